@@ -1,0 +1,85 @@
+"""ctypes loader of libbuildingsegment_hip.so (the C ABI of include/bs_api.h).
+
+Fails loudly when the HIP library is missing or cannot be loaded: there is no
+CPU fallback on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbuildingsegment_hip.so")
+
+BS_OK = 0
+STATUS = {0: "BS_OK", -1: "BS_ERR_INVALID", -2: "BS_ERR_RANGE", -3: "BS_ERR_NOMEM", -4: "BS_ERR_HIP",
+          -5: "BS_ERR_NO_DEVICE", -6: "BS_ERR_INTERNAL", -7: "BS_ERR_UNCERTIFIED"}
+
+# every symbol include/bs_api.h declares
+EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "bs_destroy", "bs_last_error",
+           "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_region_grow", "bs_segment",
+           "bs_planes_free", "bs_plane_colors", "bs_knn_normals_dev", "bs_region_grow_dev",
+           "bs_segment_dev", "bs_planes_fetch"]
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_int32), ("max_nn", C.c_int32), ("radius", C.c_double),
+                ("th_thickness", C.c_int32), ("th_point_count", C.c_int32), ("cos_th", C.c_double),
+                ("cell_size", C.c_int32), ("rg_mode", C.c_int32)]
+
+
+class Planes(C.Structure):
+    _fields_ = [("n_planes", C.c_int32), ("id", C.POINTER(C.c_int32)), ("normal", C.POINTER(C.c_double)),
+                ("center", C.POINTER(C.c_int32)), ("offset", C.POINTER(C.c_int64)),
+                ("point_idx", C.POINTER(C.c_int32))]
+
+
+class Timings(C.Structure):
+    _fields_ = [("grid_ms", C.c_double), ("knn_ms", C.c_double), ("grow_ms", C.c_double),
+                ("total_ms", C.c_double), ("largest_plane", C.c_int64), ("n_seed_attempts", C.c_int64),
+                ("n_fallback_queries", C.c_int64), ("rg_rounds", C.c_int64)]
+
+
+class BsError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__(f"{STATUS.get(status, status)}: {detail}")
+
+
+_LIB = None
+
+
+def load():
+    """dlopen the HIP library; raise if it is absent (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m buildingsegment_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp, lp = C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
+    pp = C.POINTER(Params)
+    L.bs_api_version.restype = C.c_int
+    L.bs_strerror.restype = C.c_char_p
+    L.bs_strerror.argtypes = [C.c_int]
+    L.bs_params_default.argtypes = [pp]
+    L.bs_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.bs_destroy.argtypes = [vp]
+    L.bs_destroy.restype = None
+    L.bs_last_error.argtypes = [vp]
+    L.bs_last_error.restype = C.c_char_p
+    L.bs_set_stream.argtypes = [vp, vp]
+    L.bs_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.bs_knn_normals.argtypes = [vp, ip, C.c_int64, pp, ip, dp]
+    L.bs_region_grow.argtypes = [vp, ip, dp, ip, C.c_int64, pp, ip, C.POINTER(Planes)]
+    L.bs_segment.argtypes = [vp, ip, C.c_int64, pp, ip, dp, ip, C.POINTER(Planes)]
+    L.bs_planes_free.argtypes = [C.POINTER(Planes)]
+    L.bs_planes_free.restype = None
+    L.bs_plane_colors.argtypes = [C.POINTER(Planes), ip, C.c_int64, vp]
+    L.bs_knn_normals_dev.argtypes = [vp, ip, ip, C.c_int64, C.c_int64, C.c_int64, pp, ip, dp, C.c_double, lp]
+    L.bs_region_grow_dev.argtypes = [vp, ip, dp, ip, C.c_int64, pp, ip]
+    L.bs_segment_dev.argtypes = [vp, ip, C.c_int64, pp, ip, dp, ip]
+    L.bs_planes_fetch.argtypes = [vp, C.POINTER(Planes)]
+    _LIB = L
+    return L

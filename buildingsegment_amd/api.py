@@ -1,0 +1,214 @@
+"""Python host mirror of the reference's call sites for the hot path.
+
+Reference (paths relative to /root/reference/tmc3/):
+    get_Normal_and_K_neighbor<15>(pointCloud, normal, neigh);   TMC3.cpp:215, my_function.h:48-85
+    seg_plane h(pointCloud, normal, neigh, 15);                  TMC3.cpp:216, my_function.h:98-104
+    vector<plane> planes = h.get_planes();                       TMC3.cpp:217, my_function.cpp:180-217
+    h.set_plane_color(planes);                                   TMC3.cpp:218, my_function.cpp:260-275
+
+Everything here goes through the C ABI (include/bs_api.h) into the HIP
+library; nothing is computed in Python and there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import BsError, Params, Planes, Timings
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    _lib.load().bs_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+@dataclass
+class Plane:
+    """struct plane (my_function.h:25-30)."""
+    id: int
+    normal: np.ndarray
+    center: np.ndarray
+    pointIdx: np.ndarray = field(repr=False)
+
+
+def _planes_to_list(P: Planes):
+    out = []
+    n = P.n_planes
+    if n == 0:
+        return out
+    off = np.ctypeslib.as_array(P.offset, (n + 1,))
+    ids = np.ctypeslib.as_array(P.id, (n,))
+    nrm = np.ctypeslib.as_array(P.normal, (3 * n,)).reshape(n, 3)
+    ctr = np.ctypeslib.as_array(P.center, (3 * n,)).reshape(n, 3)
+    pidx = np.ctypeslib.as_array(P.point_idx, (int(off[n]),)) if off[n] > 0 else np.zeros(0, np.int32)
+    for i in range(n):
+        out.append(Plane(int(ids[i]), nrm[i].copy(), ctr[i].copy(), pidx[off[i]:off[i + 1]].copy()))
+    return out
+
+
+class Context:
+    """bs_ctx wrapper: one HIP device, its stream and scratch buffers."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._L.bs_create(device, C.byref(self._h))
+        if rc != 0:
+            raise BsError(rc, "bs_create failed (is a gfx950 GPU visible?)")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.bs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BsError(rc, self._L.bs_last_error(self._h).decode())
+
+    def set_stream(self, stream_handle):
+        self._check(self._L.bs_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def timings(self) -> dict:
+        t = Timings()
+        self._check(self._L.bs_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+    # ---- host-buffer API ----------------------------------------------------
+    def knn_normals(self, xyz, params: Params | None = None):
+        p = params or default_params()
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise ValueError("xyz must be [n, 3]")
+        n = xyz.shape[0]
+        neigh = np.empty((n, p.k), dtype=np.int32)
+        normals = np.empty((n, 3), dtype=np.float64)
+        self._check(self._L.bs_knn_normals(self._h, xyz.ctypes.data, n, C.byref(p), neigh.ctypes.data,
+                                           normals.ctypes.data))
+        return neigh, normals
+
+    def region_grow(self, xyz, normals, neigh, params: Params | None = None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        normals = np.ascontiguousarray(normals, dtype=np.float64)
+        neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        p = params or default_params(k=neigh.shape[1])
+        if neigh.shape[1] != p.k:
+            raise ValueError("neigh width != params.k")
+        n = xyz.shape[0]
+        plane_idx = np.empty(n, dtype=np.int32)
+        P = Planes()
+        self._check(self._L.bs_region_grow(self._h, xyz.ctypes.data, normals.ctypes.data, neigh.ctypes.data,
+                                           n, C.byref(p), plane_idx.ctypes.data, C.byref(P)))
+        planes = _planes_to_list(P)
+        self._L.bs_planes_free(C.byref(P))
+        return plane_idx, planes
+
+    def segment(self, xyz, params: Params | None = None):
+        p = params or default_params()
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        n = xyz.shape[0]
+        neigh = np.empty((n, p.k), dtype=np.int32)
+        normals = np.empty((n, 3), dtype=np.float64)
+        plane_idx = np.empty(n, dtype=np.int32)
+        P = Planes()
+        self._check(self._L.bs_segment(self._h, xyz.ctypes.data, n, C.byref(p), neigh.ctypes.data,
+                                       normals.ctypes.data, plane_idx.ctypes.data, C.byref(P)))
+        planes = _planes_to_list(P)
+        self._L.bs_planes_free(C.byref(P))
+        return neigh, normals, plane_idx, planes
+
+    # ---- device-buffer API (raw device pointers, e.g. torch.Tensor.data_ptr()) ----
+    def knn_normals_dev(self, d_xyz, n, d_neigh, d_normals, params, q_begin=0, q_end=None, d_gidx=0,
+                        cert_radius=0.0):
+        q_end = n if q_end is None else q_end
+        unc = C.c_int64(0)
+        self._check(self._L.bs_knn_normals_dev(self._h, d_xyz, d_gidx or None, n, q_begin, q_end,
+                                               C.byref(params), d_neigh, d_normals or None, cert_radius,
+                                               C.byref(unc)))
+        return unc.value
+
+    def region_grow_dev(self, d_xyz, d_normals, d_neigh, n, d_plane_idx, params):
+        self._check(self._L.bs_region_grow_dev(self._h, d_xyz, d_normals, d_neigh, n, C.byref(params),
+                                               d_plane_idx))
+
+    def segment_dev(self, d_xyz, n, d_plane_idx, params, d_neigh=0, d_normals=0):
+        self._check(self._L.bs_segment_dev(self._h, d_xyz, n, C.byref(params), d_neigh or None,
+                                           d_normals or None, d_plane_idx))
+
+    def planes_fetch(self):
+        P = Planes()
+        self._check(self._L.bs_planes_fetch(self._h, C.byref(P)))
+        planes = _planes_to_list(P)
+        self._L.bs_planes_free(C.byref(P))
+        return planes
+
+
+_DEFAULT_CTX = None
+
+
+def _ctx() -> Context:
+    global _DEFAULT_CTX
+    if _DEFAULT_CTX is None:
+        _DEFAULT_CTX = Context(0)
+    return _DEFAULT_CTX
+
+
+def get_normal_and_k_neighbor(point_cloud, k: int = 15, ctx: Context | None = None):
+    """get_Normal_and_K_neighbor<K>(pointCloud, normal, neigh) (my_function.h:48-85).
+    Returns (normal [n,3] f64, neigh [n,K] int32).  The reference's stray
+    output.ply side effect (my_function.h:81) is not reproduced."""
+    neigh, normals = (ctx or _ctx()).knn_normals(point_cloud, default_params(k=k))
+    return normals, neigh
+
+
+class SegPlane:
+    """class seg_plane (my_function.h:89-123)."""
+
+    def __init__(self, point_cloud, normal, neigh, num_neigh: int, ctx: Context | None = None):
+        self.cloud = np.ascontiguousarray(point_cloud, dtype=np.int32)
+        self.normal = np.ascontiguousarray(normal, dtype=np.float64)
+        self.neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        self.K = int(num_neigh)
+        self.planeIdx = np.full(len(self.cloud), -1, dtype=np.int32)  # my_function.h:103
+        self._ctx = ctx or _ctx()
+
+    def get_planes(self):
+        """seg_plane::get_planes (my_function.cpp:180-217)."""
+        self.planeIdx, planes = self._ctx.region_grow(self.cloud, self.normal, self.neigh,
+                                                      default_params(k=self.K))
+        return planes
+
+    def set_plane_color(self, planes, rand=None):
+        """seg_plane::set_plane_color (my_function.cpp:260-275): colours [n,3]
+        uint16 in the reference's G,B,R slots.  ``rand`` is a callable returning
+        the next rand() value (default: glibc rand() seeded with 1, as an
+        unseeded C program)."""
+        if rand is None:
+            libc = C.CDLL(None)
+            libc.srand(1)
+            rand = libc.rand
+        colors = np.zeros((len(self.cloud), 3), dtype=np.uint16)
+        for p in planes:
+            col = [55 + rand() % 200, 55 + rand() % 200, 55 + rand() % 200]
+            colors[p.pointIdx] = col
+        return colors

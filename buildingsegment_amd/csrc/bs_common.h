@@ -1,0 +1,142 @@
+// bs_common.h -- shared declarations of the HIP product library
+// (libbuildingsegment_hip.so).  gfx950 only; no CUDA, no dual paths.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/bs_api.h"
+
+namespace bs {
+
+// ---- small RAII-free device buffer that only grows -----------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes)
+  {
+    if (bytes <= cap)
+      return hipSuccess;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess)
+      cap = want;
+    return e;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const
+  {
+    return (T*)p;
+  }
+};
+
+// ---- search grid (hashed uniform cells over the cell-sorted cloud) --------
+struct CellEntry {  // 16 B: one dwordx4 per probe
+  uint64_t key;     // packed cell coords, ~0 = empty slot
+  int32_t start;    // first sorted position of the cell
+  int32_t end;      // one past the last
+};
+
+struct GridDev {
+  int32_t mn[3];       // bbox min (mm)
+  int32_t dim[3];      // cells per axis (< 2^21)
+  int32_t cell;        // cell edge (mm)
+  uint32_t hmask;      // table size - 1
+  const CellEntry* table;
+  const int4* spts;    // cell-sorted points: x, y, z, global index
+  const int32_t* slocal;  // cell-sorted local (input-order) index
+  int64_t n;
+};
+
+__host__ __device__ inline uint64_t pack_cell(uint32_t cx, uint32_t cy, uint32_t cz)
+{
+  return (uint64_t)cx | ((uint64_t)cy << 21) | ((uint64_t)cz << 42);
+}
+
+__host__ __device__ inline uint32_t hash_cell(uint64_t k)
+{
+  k *= 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(k >> 32) ^ (uint32_t)k;
+}
+
+// ---- plane record produced by region growing ------------------------------
+struct PlaneRec {
+  double normal[3];
+  int64_t list_off;   // offset of pointIdx in the list pool
+  int64_t list_n;     // pointIdx.size()
+  int32_t center[3];
+  int32_t id;         // 1-based plane id
+  int32_t seed;
+  int32_t pad;
+};
+
+struct GrowStats {
+  int32_t n_planes;
+  int32_t error;        // != 0: pool overflow / watchdog
+  int64_t list_used;
+  int64_t seed_attempts;
+  int64_t largest;
+  int64_t steps;
+};
+
+}  // namespace bs
+
+// ---- context ---------------------------------------------------------------
+struct bs_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bs_timings tm{};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+  // grid scratch
+  bs::DevBuf keys_in, keys_out, vals_in, vals_out, cub_tmp, uniq_keys, uniq_cnt, misc;
+  bs::DevBuf table, spts, slocal;
+  // kNN scratch
+  bs::DevBuf fb_list, d_xyz_h, d_neigh_h, d_normals_h, d_plane_h;
+  // pipeline scratch (bs_segment_dev with NULL outputs)
+  bs::DevBuf seg_neigh, seg_normals;
+  // region-grow state
+  bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux;
+  int64_t rg_n = 0;
+  bool rg_valid = false;
+};
+
+namespace bs {
+
+int fail(bs_ctx* ctx, int status, const char* what, hipError_t e = hipSuccess);
+
+#define BS_HIP(ctx, call)                                     \
+  do {                                                        \
+    hipError_t _e = (call);                                   \
+    if (_e != hipSuccess)                                     \
+      return bs::fail((ctx), BS_ERR_HIP, #call, _e);          \
+  } while (0)
+
+// grid.hip
+int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t n, double radius,
+               int k, int cell_hint, GridDev* out);
+// knn.hip
+int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q_end,
+                       const bs_params& p, int32_t* d_neigh, double* d_normals, double cert_radius,
+                       int64_t* n_uncertified);
+// grow.hip
+int launch_region_grow(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals,
+                       const int32_t* d_neigh, int64_t n, const bs_params& p,
+                       int32_t* d_plane_idx);
+
+}  // namespace bs

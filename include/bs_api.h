@@ -1,0 +1,166 @@
+/*
+ * bs_api.h -- C ABI of the MI355X-native buildingSegment hot path
+ * (kNN neighbourhood build -> PCA normal estimation -> region-growing plane
+ * labelling).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Reference interfaces this boundary replaces (all paths relative to
+ * /root/reference/):
+ *   tmc3/TMC3.cpp:213-218        the four call-site lines in main()
+ *   tmc3/my_function.h:48-85     get_Normal_and_K_neighbor<K>()      -> bs_knn_normals*
+ *   tmc3/my_function.h:89-123    class seg_plane (ctor, get_planes)  -> bs_region_grow*
+ *   tmc3/my_function.cpp:180-258 seg_plane::get_planes / Broad       -> bs_region_grow*
+ *   tmc3/my_function.h:25-30     struct plane                        -> bs_planes (CSR)
+ *   tmc3/my_function.cpp:260-275 seg_plane::set_plane_color          -> bs_plane_colors
+ *   tmc3/PCCPointSet.h:60,67,605 positions (int32 AoS) / planeIdx    -> xyz / plane_idx buffers
+ *
+ * Conventions
+ *   - xyz is the reference's AoS layout: int32 [n][3] millimetres == &cloud[0].
+ *   - neigh is row-major int32 [n][k], nearest first, ties (equal squared
+ *     distance) broken by ascending point index, self included.
+ *   - normals are f64 [n][3], unit length, oriented to +z.
+ *   - plane_idx is int32 [n]: -1 = unlabelled, >=1 = plane id (orphans of
+ *     failed seeds carry the id of the next committed plane, exactly as the
+ *     reference leaves them).
+ *   - every function returns BS_OK (0) or a negative bs_status; nothing aborts.
+ *   - *_dev entry points take DEVICE pointers, enqueue on the context's
+ *     stream and do not synchronise unless stated.
+ *   - a bs_ctx is owned by one host thread at a time.
+ */
+#ifndef BS_API_H
+#define BS_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BS_API_VERSION 1
+
+typedef enum bs_status {
+  BS_OK = 0,
+  BS_ERR_INVALID = -1,     /* null pointer, n < k, k out of range, bad params */
+  BS_ERR_RANGE = -2,       /* coordinates outside the exactly-representable domain */
+  BS_ERR_NOMEM = -3,       /* host or device allocation failed */
+  BS_ERR_HIP = -4,         /* HIP runtime error (see bs_last_error) */
+  BS_ERR_NO_DEVICE = -5,   /* no usable gfx950 device */
+  BS_ERR_INTERNAL = -6,    /* invariant violated (watchdog, overflow of a work list) */
+  BS_ERR_UNCERTIFIED = -7  /* halo too thin: some queries could not be certified */
+} bs_status;
+
+/* Parameters.  Defaults are the reference's literals:
+ *   k 15 (TMC3.cpp:215-216), radius 100 / max_nn 50 (my_function.h:63),
+ *   th_thickness 300, th_point_count 400 (my_function.h:117-118),
+ *   cos_th 0.88 (my_function.cpp:230). */
+typedef struct bs_params {
+  int32_t k;              /* neighbour-list length, 2..32 */
+  int32_t max_nn;         /* hybrid search cap for normals, 3..64 */
+  double radius;          /* hybrid search radius (mm), strict d^2 < radius^2 */
+  int32_t th_thickness;   /* region grow: |distance to plane| <= th_thickness */
+  int32_t th_point_count; /* keep a plane iff pointIdx.size() > th_point_count */
+  double cos_th;          /* region grow: cur_normal . normal[id] >= cos_th */
+  int32_t cell_size;      /* search-grid cell edge in mm, 0 = choose automatically */
+  int32_t rg_mode;        /* 0 = auto, 1 = single-wave sequential, 2 = multi-plane speculative */
+} bs_params;
+
+/* CSR form of std::vector<plane> (my_function.h:25-30), in the reference's
+ * commit order.  point_idx keeps the reference's list order and duplicates
+ * (the seed can appear twice).  Arrays are owned by the library after a
+ * successful call and released by bs_planes_free. */
+typedef struct bs_planes {
+  int32_t n_planes;
+  int32_t* id;        /* [n_planes]   plane::id (1-based)            */
+  double* normal;     /* [n_planes*3] plane::normal                  */
+  int32_t* center;    /* [n_planes*3] plane::center                  */
+  int64_t* offset;    /* [n_planes+1] CSR offsets into point_idx     */
+  int32_t* point_idx; /* [offset[n_planes]] plane::pointIdx, in order */
+} bs_planes;
+
+/* Per-call stage timings (milliseconds of device time, HIP events on the
+ * context's stream) of the last *_dev / host call. */
+typedef struct bs_timings {
+  double grid_ms;    /* cell keys + sort + cell table                */
+  double knn_ms;     /* kNN + normals kernels (incl. fallback rings) */
+  double grow_ms;    /* region growing                               */
+  double total_ms;   /* first kernel to last kernel                  */
+  int64_t largest_plane;  /* pointIdx.size() of the largest committed plane */
+  int64_t n_seed_attempts;
+  int64_t n_fallback_queries; /* queries that left the LDS-tile fast path */
+  int64_t rg_rounds;      /* speculative rounds (rg_mode 2) */
+} bs_timings;
+
+typedef struct bs_ctx bs_ctx;
+
+int bs_api_version(void);
+const char* bs_strerror(int status);
+void bs_params_default(bs_params* p);
+
+/* Context: binds one HIP device; owns the stream and all scratch buffers. */
+int bs_create(int device, bs_ctx** out);
+void bs_destroy(bs_ctx* ctx);
+const char* bs_last_error(const bs_ctx* ctx);
+/* Use an existing hipStream_t (e.g. the caller's current stream); NULL
+ * restores the context's own stream. */
+int bs_set_stream(bs_ctx* ctx, void* hip_stream);
+int bs_get_timings(const bs_ctx* ctx, bs_timings* out);
+
+/* ---- host-buffer entry points (what the reference's call sites bind) ---- */
+
+/* Replaces get_Normal_and_K_neighbor<K>() (my_function.h:48-85). */
+int bs_knn_normals(bs_ctx* ctx, const int32_t* xyz, int64_t n, const bs_params* p,
+                   int32_t* neigh /* [n][k] out */, double* normals /* [n][3] out */);
+
+/* Replaces seg_plane::seg_plane + get_planes (my_function.h:98-104,
+ * my_function.cpp:180-258). */
+int bs_region_grow(bs_ctx* ctx, const int32_t* xyz, const double* normals,
+                   const int32_t* neigh, int64_t n, const bs_params* p,
+                   int32_t* plane_idx /* [n] out */, bs_planes* planes /* out, may be NULL */);
+
+/* Whole path, device-resident between the stages (TMC3.cpp:213-217). */
+int bs_segment(bs_ctx* ctx, const int32_t* xyz, int64_t n, const bs_params* p,
+               int32_t* neigh /* may be NULL */, double* normals /* may be NULL */,
+               int32_t* plane_idx, bs_planes* planes /* may be NULL */);
+
+void bs_planes_free(bs_planes* planes);
+
+/* Replaces seg_plane::set_plane_color (my_function.cpp:260-275): colours
+ * [n][3] uint16 in the reference's internal G,B,R slot order, all zero, then
+ * one colour per plane applied to every pointIdx entry.  plane_rgb is
+ * [n_planes][3], the values the caller drew (the reference draws
+ * 55 + rand() % 200 three times per plane). */
+int bs_plane_colors(const bs_planes* planes, const int32_t* plane_rgb, int64_t n,
+                    uint16_t* colors /* [n][3] out */);
+
+/* ---- device-buffer entry points (the measured path) ---- */
+
+/* kNN + normals for the queries [q_begin, q_end) of a device-resident cloud of
+ * n points.  d_gidx (nullable) gives the global index of each local point
+ * (used for tie-breaking and written into d_neigh); NULL = identity.
+ * Outputs are indexed by (query - q_begin).  cert_radius > 0 certifies a
+ * k-list only if its k-th distance is < cert_radius (halo mode);
+ * *n_uncertified (host, nullable) receives the number of failures after a
+ * stream sync. */
+int bs_knn_normals_dev(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t n,
+                       int64_t q_begin, int64_t q_end, const bs_params* p,
+                       int32_t* d_neigh, double* d_normals, double cert_radius,
+                       int64_t* n_uncertified);
+
+/* Region growing on device-resident inputs; d_plane_idx [n] out.  Plane
+ * records stay on the device until bs_planes_fetch. Synchronises the stream
+ * (the speculative scheduler is host-driven). */
+int bs_region_grow_dev(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals,
+                       const int32_t* d_neigh, int64_t n, const bs_params* p,
+                       int32_t* d_plane_idx);
+
+/* Fused device-resident pipeline: xyz in HBM -> plane_idx in HBM.
+ * d_neigh / d_normals may be NULL (scratch owned by the context is used). */
+int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params* p,
+                   int32_t* d_neigh, double* d_normals, int32_t* d_plane_idx);
+
+/* Copy the plane records of the last region-grow on this context to the host. */
+int bs_planes_fetch(bs_ctx* ctx, bs_planes* planes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BS_API_H */
