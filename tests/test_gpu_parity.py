@@ -64,3 +64,96 @@ def test_segment_fused_matches_stages(gpu_ctx, oracle):
     opi, opl = oracle.region_grow(xyz, onormals, oneigh)
     assert np.array_equal(plane_idx, opi)
     assert sum(len(p.pointIdx) for p in planes) == len(opl["point_idx"])
+
+
+# ---- golden fixtures: the reference's own stage-3 outputs (tests/golden) ----
+import glob
+import os
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_region_grow_matches_reference_golden(gpu_ctx, path):
+    g = np.load(path)
+    k = g["neigh"].shape[1]
+    pi, planes = gpu_ctx.region_grow(g["xyz"], g["normals"], g["neigh"], api.default_params(k=k))
+    assert np.array_equal(pi, g["plane_idx"])
+    assert [p.id for p in planes] == g["id"].tolist()
+    for i, p in enumerate(planes):
+        assert np.array_equal(p.pointIdx, g["point_idx"][g["offset"][i]:g["offset"][i + 1]])
+        assert np.array_equal(p.center, g["center"][i])
+        assert np.array_equal(p.normal, g["normal"][i])
+
+
+def test_legacy_adapter_colours_match_reference(gpu_ctx):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "plane_cube_12k.npz"))
+    h = api.SegPlane(g["xyz"], g["normals"], g["neigh"], 15, ctx=gpu_ctx)
+    planes = h.get_planes()
+    assert np.array_equal(h.planeIdx, g["plane_idx"])
+    assert np.array_equal(h.set_plane_color(planes), g["colors"])  # glibc rand(), G,B,R slots
+
+
+# ---- edge cases ----------------------------------------------------------------
+
+def test_duplicates_and_exact_ties(gpu_ctx, oracle):
+    rng = np.random.default_rng(5)
+    xyz = (rng.integers(0, 12, (5000, 3)) * 25).astype(np.int32)  # heavy duplication, ties everywhere
+    neigh, normals = _check_knn_normals(gpu_ctx, oracle, xyz, 15)
+    _check_grow(gpu_ctx, oracle, xyz, normals, neigh)
+
+
+def test_dense_ball_exceeds_max_nn(gpu_ctx, oracle):
+    rng = np.random.default_rng(9)
+    xyz = rng.integers(0, 150, (6000, 3)).astype(np.int32)  # > 50 points inside every r=100 ball
+    _check_knn_normals(gpu_ctx, oracle, xyz, 16)
+    assert gpu_ctx.timings()["n_fallback_queries"] > 0
+
+
+def test_sparse_outliers_need_far_rings(gpu_ctx, oracle):
+    a = synth.uniform(4000, seed=4)
+    far = np.array([[200000, 5, 5], [5, 300000, 7], [400000, 400000, 400000], [-90000, 0, 0]], np.int32)
+    xyz = np.concatenate([a, far]).astype(np.int32)
+    _check_knn_normals(gpu_ctx, oracle, xyz, 15)
+
+
+def test_n_equals_k(gpu_ctx, oracle):
+    xyz = synth.uniform(16, seed=8)
+    neigh, normals = _check_knn_normals(gpu_ctx, oracle, xyz, 16)
+    _check_grow(gpu_ctx, oracle, xyz, normals, neigh)
+
+
+def test_explicit_cell_size_and_thresholds(gpu_ctx, oracle):
+    xyz = synth.plane_cube()[:40000].copy()
+    ref = _check_knn_normals(gpu_ctx, oracle, xyz, 15)
+    for cell in (60, 333, 9000):  # 9000 mm forces the general kernel for every query
+        p = api.default_params(k=15, cell_size=cell)
+        ng, nr = gpu_ctx.knn_normals(xyz, p)
+        assert np.array_equal(ng, ref[0]) and np.array_equal(nr, ref[1])
+    _check_grow(gpu_ctx, oracle, xyz, ref[1], ref[0], th_thickness=40, th_point_count=50, cos_th=0.97)
+
+
+def test_error_codes(gpu_ctx):
+    xyz = synth.uniform(10, seed=1)
+    with pytest.raises(api.BsError) as e:
+        gpu_ctx.knn_normals(xyz, api.default_params(k=15))  # n < k: the reference is UB here
+    assert e.value.status == -1
+    with pytest.raises(api.BsError) as e:
+        gpu_ctx.knn_normals(synth.uniform(100, seed=1), api.default_params(k=40))
+    assert e.value.status == -1
+    big = synth.uniform(100, seed=1).copy()
+    big[0, 0] = 1 << 24
+    with pytest.raises(api.BsError) as e:
+        gpu_ctx.knn_normals(big, api.default_params(k=15))
+    assert e.value.status == -2
+    bad = np.zeros((100, 15), np.int32)
+    bad[3, 3] = 100
+    with pytest.raises(api.BsError) as e:
+        gpu_ctx.region_grow(synth.uniform(100, seed=1), np.tile([0.0, 0.0, 1.0], (100, 1)), bad,
+                            api.default_params(k=15))
+    assert e.value.status == -1
+
+
+def test_negative_coordinates_without_shift(gpu_ctx, oracle):
+    xyz = synth.plane_cube()[:20000].astype(np.int64) - 4000
+    _check_knn_normals(gpu_ctx, oracle, xyz.astype(np.int32), 15)
