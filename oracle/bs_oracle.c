@@ -492,6 +492,19 @@ int bso_knn_normals(const int32_t* xyz, int64_t n, int64_t q0, int64_t q1, int k
     const int64_t qq[3] = {qx, qy, qz};
     int kc = 0, mc = 0;
     for (int64_t rho = 0;; rho++) {
+      if (rho > 8) {
+        /* isolated query: rings get expensive, a full scan is just as exact */
+        kc = 0;
+        mc = 0;
+        for (int64_t j = 0; j < n; j++) {
+          int64_t ddx = xyz[3 * j] - qx, ddy = xyz[3 * j + 1] - qy, ddz = xyz[3 * j + 2] - qz;
+          uint64_t d2 = (uint64_t)(ddx * ddx) + (uint64_t)(ddy * ddy) + (uint64_t)(ddz * ddz);
+          topk_insert(kb, &kc, k, d2, (int32_t)j);
+          if (normals && (double)d2 < r2)
+            topk_insert(mb, &mc, max_nn, d2, (int32_t)j);
+        }
+        break;
+      }
       for (int64_t dz = -rho; dz <= rho; dz++) {
         int64_t cz = ci[2] + dz;
         if (cz < 0 || cz >= g.dim[2])
