@@ -38,6 +38,8 @@ static int check_params(bs_ctx* ctx, const bs_params* p, int64_t n)
     return fail(ctx, BS_ERR_INVALID, "n < k (the reference is undefined there)");
   if (n >= (int64_t)INT32_MAX - 64)
     return fail(ctx, BS_ERR_INVALID, "n must fit in int32");
+  if (p->rg_mode < 0 || p->rg_mode > 2)
+    return fail(ctx, BS_ERR_INVALID, "rg_mode must be 0, 1 or 2");
   return BS_OK;
 }
 
@@ -209,7 +211,10 @@ int bs_region_grow_dev(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normal
   BS_HIP(ctx, hipSetDevice(ctx->device));
   EventTimer T(ctx);
   T.mark(3);
-  rc = launch_region_grow(ctx, d_xyz, d_normals, d_neigh, n, *p, d_plane_idx);
+  if (p->rg_mode == 1)
+    rc = launch_region_grow_seq(ctx, d_xyz, d_normals, d_neigh, n, *p, d_plane_idx);
+  else
+    rc = launch_region_grow_spec(ctx, d_xyz, d_normals, d_neigh, n, *p, d_plane_idx);
   if (rc != BS_OK)
     return rc;
   T.mark(4);

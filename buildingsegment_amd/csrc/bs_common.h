@@ -135,8 +135,12 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
                        const bs_params& p, int32_t* d_neigh, double* d_normals, double cert_radius,
                        int64_t* n_uncertified);
 // grow.hip
-int launch_region_grow(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals,
-                       const int32_t* d_neigh, int64_t n, const bs_params& p,
-                       int32_t* d_plane_idx);
+int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals,
+                           const int32_t* d_neigh, int64_t n, const bs_params& p,
+                           int32_t* d_plane_idx);
+// grow_spec.hip
+int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals,
+                            const int32_t* d_neigh, int64_t n, const bs_params& p,
+                            int32_t* d_plane_idx);
 
 }  // namespace bs

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void grow_seq_kernel(GrowArgs a)
 
 }  // namespace
 
-int launch_region_grow(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
+int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
                        int64_t n, const bs_params& p, int32_t* d_plane_idx)
 {
   hipStream_t st = ctx->stream;

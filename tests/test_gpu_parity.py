@@ -21,8 +21,18 @@ def _check_knn_normals(ctx, O, xyz, k, **kw):
     return neigh, normals
 
 
+RG_MODES = (1, 2)  # 1 = single-wave sequential, 2 = multi-plane speculative (the default)
+
+
 def _check_grow(ctx, O, xyz, normals, neigh, **kw):
-    p = api.default_params(k=neigh.shape[1], **kw)
+    out = None
+    for mode in RG_MODES:
+        out = _check_grow_mode(ctx, O, xyz, normals, neigh, mode, **kw)
+    return out
+
+
+def _check_grow_mode(ctx, O, xyz, normals, neigh, mode, **kw):
+    p = api.default_params(k=neigh.shape[1], rg_mode=mode, **kw)
     plane_idx, planes = ctx.region_grow(xyz, normals, neigh, p)
     opi, opl = O.region_grow(xyz, normals, neigh, th_thickness=p.th_thickness,
                              th_point_count=p.th_point_count, cos_th=p.cos_th)
@@ -73,11 +83,12 @@ import os
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
 
+@pytest.mark.parametrize("mode", RG_MODES)
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
-def test_region_grow_matches_reference_golden(gpu_ctx, path):
+def test_region_grow_matches_reference_golden(gpu_ctx, path, mode):
     g = np.load(path)
     k = g["neigh"].shape[1]
-    pi, planes = gpu_ctx.region_grow(g["xyz"], g["normals"], g["neigh"], api.default_params(k=k))
+    pi, planes = gpu_ctx.region_grow(g["xyz"], g["normals"], g["neigh"], api.default_params(k=k, rg_mode=mode))
     assert np.array_equal(pi, g["plane_idx"])
     assert [p.id for p in planes] == g["id"].tolist()
     for i, p in enumerate(planes):
