@@ -17,7 +17,7 @@ STATUS = {0: "BS_OK", -1: "BS_ERR_INVALID", -2: "BS_ERR_RANGE", -3: "BS_ERR_NOME
 
 # every symbol include/bs_api.h declares
 EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "bs_destroy", "bs_last_error",
-           "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_region_grow", "bs_segment",
+           "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_knn_normals_halo", "bs_region_grow", "bs_segment",
            "bs_planes_free", "bs_plane_colors", "bs_knn_normals_dev", "bs_region_grow_dev",
            "bs_segment_dev", "bs_planes_fetch"]
 
@@ -72,6 +72,7 @@ def load():
     L.bs_set_stream.argtypes = [vp, vp]
     L.bs_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.bs_knn_normals.argtypes = [vp, ip, C.c_int64, pp, ip, dp]
+    L.bs_knn_normals_halo.argtypes = [vp, ip, ip, C.c_int64, C.c_int64, pp, ip, dp, C.c_double, lp]
     L.bs_region_grow.argtypes = [vp, ip, dp, ip, C.c_int64, pp, ip, C.POINTER(Planes)]
     L.bs_segment.argtypes = [vp, ip, C.c_int64, pp, ip, dp, ip, C.POINTER(Planes)]
     L.bs_planes_free.argtypes = [C.POINTER(Planes)]

@@ -107,6 +107,20 @@ class Context:
                                            normals.ctypes.data))
         return neigh, normals
 
+    def knn_normals_halo(self, xyz_local, gidx, n_query, params: Params, cert_radius: float):
+        """Slab form: the first n_query points are queries, the rest halo; returns
+        (neigh with GLOBAL indices, normals, number of uncertified k-lists)."""
+        xyz_local = np.ascontiguousarray(xyz_local, dtype=np.int32)
+        gidx = np.ascontiguousarray(gidx, dtype=np.int32)
+        n = xyz_local.shape[0]
+        neigh = np.empty((n_query, params.k), dtype=np.int32)
+        normals = np.empty((n_query, 3), dtype=np.float64)
+        unc = C.c_int64(0)
+        self._check(self._L.bs_knn_normals_halo(self._h, xyz_local.ctypes.data, gidx.ctypes.data, n, n_query,
+                                                C.byref(params), neigh.ctypes.data, normals.ctypes.data,
+                                                float(cert_radius), C.byref(unc)))
+        return neigh, normals, unc.value
+
     def region_grow(self, xyz, normals, neigh, params: Params | None = None):
         xyz = np.ascontiguousarray(xyz, dtype=np.int32)
         normals = np.ascontiguousarray(normals, dtype=np.float64)

@@ -353,6 +353,40 @@ int bs_knn_normals(bs_ctx* ctx, const int32_t* xyz, int64_t n, const bs_params* 
   return BS_OK;
 }
 
+int bs_knn_normals_halo(bs_ctx* ctx, const int32_t* xyz, const int32_t* gidx, int64_t n, int64_t n_query,
+                        const bs_params* p, int32_t* neigh, double* normals, double cert_radius,
+                        int64_t* n_uncertified)
+{
+  if (!ctx)
+    return BS_ERR_INVALID;
+  if (!xyz || !gidx || !neigh || !normals)
+    return fail(ctx, BS_ERR_INVALID, "null host pointer");
+  int rc = check_params(ctx, p, n);
+  if (rc != BS_OK)
+    return rc;
+  if (n_query < 0 || n_query > n)
+    return fail(ctx, BS_ERR_INVALID, "bad n_query");
+  for (int64_t i = 0; i < n; i++)
+    if (gidx[i] < 0)
+      return fail(ctx, BS_ERR_INVALID, "negative global index");
+  BS_HIP(ctx, hipSetDevice(ctx->device));
+  BS_HIP(ctx, ctx->d_xyz_h.reserve(sizeof(int32_t) * 3 * n));
+  BS_HIP(ctx, ctx->d_plane_h.reserve(sizeof(int32_t) * n));  // staging for gidx
+  BS_HIP(ctx, ctx->d_neigh_h.reserve(sizeof(int32_t) * std::max<int64_t>(n_query, 1) * p->k));
+  BS_HIP(ctx, ctx->d_normals_h.reserve(sizeof(double) * 3 * std::max<int64_t>(n_query, 1)));
+  hipStream_t st = ctx->stream;
+  BS_HIP(ctx, hipMemcpyAsync(ctx->d_xyz_h.p, xyz, sizeof(int32_t) * 3 * n, hipMemcpyHostToDevice, st));
+  BS_HIP(ctx, hipMemcpyAsync(ctx->d_plane_h.p, gidx, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+  rc = bs_knn_normals_dev(ctx, ctx->d_xyz_h.as<int32_t>(), ctx->d_plane_h.as<int32_t>(), n, 0, n_query, p,
+                          ctx->d_neigh_h.as<int32_t>(), ctx->d_normals_h.as<double>(), cert_radius, n_uncertified);
+  if (rc != BS_OK)
+    return rc;
+  BS_HIP(ctx, hipMemcpyAsync(neigh, ctx->d_neigh_h.p, sizeof(int32_t) * n_query * p->k, hipMemcpyDeviceToHost, st));
+  BS_HIP(ctx, hipMemcpyAsync(normals, ctx->d_normals_h.p, sizeof(double) * 3 * n_query, hipMemcpyDeviceToHost, st));
+  BS_HIP(ctx, hipStreamSynchronize(st));
+  return BS_OK;
+}
+
 int bs_region_grow(bs_ctx* ctx, const int32_t* xyz, const double* normals, const int32_t* neigh, int64_t n,
                    const bs_params* p, int32_t* plane_idx, bs_planes* planes)
 {

@@ -34,6 +34,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "bs_common.h"
@@ -57,6 +59,7 @@ struct SpecArgs {
   double cos_th;
   int64_t th_count;
   int32_t F;  // every attempt < F is final
+  int32_t vec;  // neighbour rows are 16-byte aligned: int4 row loads/stores
 };
 
 struct PlaneOut {
@@ -113,6 +116,7 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int64_t used, int6
     ncap = need;
   if (ncap < 2048)
     ncap = 2048;
+  ncap = (ncap + 3) & ~(int64_t)3;  // keep slab offsets 16-byte aligned (int4 stack slots)
   unsigned long long off = 0;
   if (lane == 0)
     off = atomicAdd(pool.top, (unsigned long long)ncap);
@@ -199,6 +203,13 @@ __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int32
 }
 
 // ---- (b) speculative plane growth: one wavefront per candidate seed -------------
+// Step engine: every lane that gathers a neighbour also prefetches that
+// neighbour's own neighbour row, so the next Broad() call (first accepted
+// child) starts from registers, and the other accepted children are pushed on
+// the LIFO together with their rows (slot 0 of a row is never read by Broad,
+// :224, so it carries the point id).  One dependent HBM round trip per step
+// instead of three (pop -> row -> gather).
+template <int KC>
 __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t* __restrict__ cand, int ncand,
                                                        const int32_t* __restrict__ omega, int32_t* tag, Pool pool,
                                                        PlaneOut* __restrict__ out, int64_t step_cap)
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     return;
   const int lane = threadIdx.x;
   const int K = a.K, nc = K - 1;
+  const bool vec = a.vec != 0;
   const int32_t seed = cand[w];
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
   int64_t ln = 1, sp = 0, logn = 0, steps = 0;
@@ -217,24 +229,27 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   int ccx = a.xyz[3 * (int64_t)seed], ccy = a.xyz[3 * (int64_t)seed + 1], ccz = a.xyz[3 * (int64_t)seed + 2];
   double Sx = 0.0 + cnx, Sy = 0.0 + cny, Sz = 0.0 + cnz;
   uint32_t Cx = (uint32_t)ccx, Cy = (uint32_t)ccy, Cz = (uint32_t)ccz;
-  if (!slab_ensure(pool, list, 0, 2048, lane) || !slab_ensure(pool, stack, 0, 2048, lane) ||
+  if (!slab_ensure(pool, list, 0, 2048, lane) || !slab_ensure(pool, stack, 0, 256 * (int64_t)K, lane) ||
       !slab_ensure(pool, log, 0, 2048, lane)) {
     status = ST_NOMEM;
   } else {
     if (lane == 0)
       pool.base[list.off] = seed;
-    int64_t cur = seed;
+    const bool act = lane < nc;
+    int cand_id = act ? a.neigh[(int64_t)seed * K + lane + 1] : 0;
     bool depth0 = true;
     for (;;) {
       if (++steps > step_cap) {
         status = ST_WATCHDOG;
         break;
       }
-      const bool act = lane < nc;
-      int cand_id = 0, own = 0, tg = INF, px = 0, py = 0, pz = 0;
+      int own = 0, tg = INF, px = 0, py = 0, pz = 0;
       double mx = 0, my = 0, mz = 0;
+      int row[KC];
+#pragma unroll
+      for (int j = 0; j < KC; j++)
+        row[j] = 0;
       if (act) {
-        cand_id = a.neigh[cur * K + lane + 1];
         own = omega[cand_id];
         tg = ld_i32(tag + cand_id);
         px = a.xyz[3 * (int64_t)cand_id];
@@ -243,6 +258,23 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         mx = a.normals[3 * (int64_t)cand_id];
         my = a.normals[3 * (int64_t)cand_id + 1];
         mz = a.normals[3 * (int64_t)cand_id + 2];
+        const int32_t* rp = a.neigh + (int64_t)cand_id * K;
+        if (vec) {
+#pragma unroll
+          for (int j = 0; j < KC; j += 4)
+            if (j < K) {
+              const int4 v = *reinterpret_cast<const int4*>(rp + j);
+              row[j] = v.x;
+              row[j + 1] = v.y;
+              row[j + 2] = v.z;
+              row[j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+          for (int j = 1; j < KC; j++)
+            if (j < K)
+              row[j] = rp[j];
+        }
       }
       bool geo = false;
       if (act && tg != seed) {  // tg == seed: already labelled by this plane
@@ -281,7 +313,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       }
       depth0 = false;
       if (cnt) {
-        if (!slab_ensure(pool, list, ln, ln + cnt, lane) || !slab_ensure(pool, stack, sp, sp + cnt, lane)) {
+        if (!slab_ensure(pool, list, ln, ln + cnt, lane) ||
+            !slab_ensure(pool, stack, sp * K, (sp + cnt) * K, lane)) {
           status = ST_NOMEM;
           break;
         }
@@ -308,15 +341,37 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);
         ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
         ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
-        if (ok && rank > 0)
-          pool.base[stack.off + sp + (cnt - 1 - rank)] = cand_id;
+        // children 2..cnt go on the LIFO (reversed) with their rows; id in slot 0
+        if (ok && rank > 0) {
+          int32_t* slot = pool.base + stack.off + (sp + (cnt - 1 - rank)) * K;
+          row[0] = cand_id;
+          if (vec) {
+#pragma unroll
+            for (int j = 0; j < KC; j += 4)
+              if (j < K)
+                *reinterpret_cast<int4*>(slot + j) = make_int4(row[j], row[j + 1], row[j + 2], row[j + 3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < KC; j++)
+              if (j < K)
+                slot[j] = row[j];
+          }
+        }
         sp += cnt - 1;
-        cur = readlane_i32(cand_id, __ffsll(am) - 1);
+        // first child continues from registers: lane l takes row_f[l + 1]
+        const int f = __ffsll(am) - 1;
+        int nxt = 0;
+#pragma unroll
+        for (int j = 1; j < KC; j++) {
+          const int t = readlane_i32(row[j], f);
+          nxt = (lane == j - 1) ? t : nxt;
+        }
+        cand_id = nxt;
       } else {
         if (sp == 0)
           break;
         sp--;
-        cur = ld_i32(pool.base + stack.off + sp);
+        cand_id = act ? ld_i32(pool.base + stack.off + sp * K + lane + 1) : 0;
       }
     }
   }
@@ -488,7 +543,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;
   // round pool: lists + stacks + logs of every concurrent attempt
   const unsigned long long pool_cap =
-      (unsigned long long)std::max<int64_t>(std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + 6 * 2048 * MAX_WAVES);
+      (unsigned long long)std::max<int64_t>(std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * K) * 2 * MAX_WAVES);
   BS_HIP(ctx, ctx->rg_list.reserve(sizeof(int32_t) * list_cap));
   BS_HIP(ctx, ctx->rg_planes.reserve(sizeof(PlaneRec) * planes_cap));
   BS_HIP(ctx, ctx->rg_stats.reserve(sizeof(GrowStats)));
@@ -524,6 +579,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   a.cos_th = p.cos_th;
   a.th_count = p.th_point_count;
   a.F = 0;
+  a.vec = ((K & 3) == 0 && ((uintptr_t)d_neigh & 15) == 0) ? 1 : 0;
 
   static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, hmask);
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, INF);
@@ -568,7 +624,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // grow them concurrently
     fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(tag, n, INF);
     BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
-    grow_spec_kernel<<<ncand, 64, 0, st>>>(a, d_cand, ncand, omega, tag, pool, d_out, 512 * n + 4096);
+    if (K <= 16)
+      grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, omega, tag, pool, d_out, 512 * n + 4096);
+    else
+      grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, omega, tag, pool, d_out, 512 * n + 4096);
     validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, tag, ps);
     // owner base with the finished planes inserted, then the new fixed point
     BS_HIP(ctx, hipMemcpyAsync(base, owner_final, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
@@ -602,6 +661,23 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       if (max_waves == 1)
         return fail(ctx, BS_ERR_NOMEM, "region grow (speculative): round pool exhausted");
       max_waves = std::max(1, max_waves / 8);
+    }
+    if (getenv("BS_DEBUG")) {
+      int cnt[6] = {0, 0, 0, 0, 0, 0}, cons = 0;
+      int64_t maxsteps = 0, sumsteps = 0, maxlist = 0;
+      for (int w = 0; w < ncand; w++) {
+        cnt[h_out[w].status]++;
+        cons += h_out[w].status == ST_DONE && h_out[w].consistent;
+        maxsteps = std::max(maxsteps, h_out[w].steps);
+        sumsteps += h_out[w].steps;
+        maxlist = std::max(maxlist, h_out[w].list_n);
+      }
+      fprintf(stderr,
+              "[bs] round %ld F=%d ncand_all=%d grown=%d done=%d (consistent %d) failed0=%d nomem=%d stolen=%d "
+              "first_bad=%d new_min=%d lowest=%d highest=%d maxsteps=%ld sumsteps=%ld maxlist=%ld passes=%ld\n",
+              (long)rounds, F, ncand_all, ncand, cnt[ST_DONE], cons, cnt[ST_FAILED0], cnt[ST_NOMEM], cnt[ST_STOLEN],
+              first_bad, new_min, h_out[0].seed, h_out[ncand - 1].seed, (long)maxsteps, (long)sumsteps,
+              (long)maxlist, (long)passes);
     }
     // commit everything below first_bad, in seed order (cand is sorted)
     int finals = 0;

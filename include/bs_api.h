@@ -121,6 +121,15 @@ int bs_segment(bs_ctx* ctx, const int32_t* xyz, int64_t n, const bs_params* p,
                int32_t* neigh /* may be NULL */, double* normals /* may be NULL */,
                int32_t* plane_idx, bs_planes* planes /* may be NULL */);
 
+/* Halo (multi-GPU slab) form of bs_knn_normals: the first n_query points of a
+ * local cloud are the queries, the rest is halo; gidx [n] gives every local
+ * point's global index (ties are broken by it and neigh holds global
+ * indices).  A k-list is certified iff its k-th distance < cert_radius (the
+ * halo width); *n_uncertified counts the failures (results are still written). */
+int bs_knn_normals_halo(bs_ctx* ctx, const int32_t* xyz, const int32_t* gidx, int64_t n, int64_t n_query,
+                        const bs_params* p, int32_t* neigh /* [n_query][k] */, double* normals /* [n_query][3] */,
+                        double cert_radius, int64_t* n_uncertified);
+
 void bs_planes_free(bs_planes* planes);
 
 /* Replaces seg_plane::set_plane_color (my_function.cpp:260-275): colours

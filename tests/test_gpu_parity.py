@@ -168,3 +168,31 @@ def test_error_codes(gpu_ctx):
 def test_negative_coordinates_without_shift(gpu_ctx, oracle):
     xyz = synth.plane_cube()[:20000].astype(np.int64) - 4000
     _check_knn_normals(gpu_ctx, oracle, xyz.astype(np.int32), 15)
+
+
+def test_halo_slab_form_matches_global_result(gpu_ctx, oracle):
+    """bs_knn_normals_halo (the per-GPU piece of the sharded path): two Morton
+    slabs processed one after the other on this GPU must reproduce the global
+    neighbour indices / normals; a thin halo must be reported as uncertified."""
+    from buildingsegment_amd import dist as bsd
+    xyz = synth.plane_cube()[:30000].copy()
+    p = api.default_params(k=15)
+    ng, nr = oracle.knn_normals(xyz, k=15)
+    for r in range(2):
+        own_xyz, own_idx = bsd.partition_morton(xyz, 2, r)
+        other = np.setdiff1d(np.arange(len(xyz)), own_idx)
+        for h, expect_ok in ((300.0, True), (20.0, False)):
+            # halo = every foreign point within h (L-inf) of some own point: brute force via voxels of edge h
+            v = int(h)
+            own_vox = set(map(tuple, (own_xyz // v)))
+            ov = xyz[other] // v
+            near = np.array([any((a + dx, b + dy, c + dz) in own_vox for dx in (-1, 0, 1) for dy in (-1, 0, 1)
+                                 for dz in (-1, 0, 1)) for a, b, c in ov])
+            loc_xyz = np.concatenate([own_xyz, xyz[other][near]]).astype(np.int32)
+            loc_idx = np.concatenate([own_idx, other[near].astype(np.int32)]).astype(np.int32)
+            neigh, normals, unc = gpu_ctx.knn_normals_halo(loc_xyz, loc_idx, len(own_idx), p, h)
+            if expect_ok:
+                assert unc == 0
+                assert np.array_equal(neigh, ng[own_idx]) and np.array_equal(normals, nr[own_idx])
+            else:
+                assert unc > 0
