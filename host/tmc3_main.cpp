@@ -56,6 +56,10 @@ int main(int argc, char* argv[])
     bs::get_Normal_and_K_neighbor<15>(cloud, normal, neigh);
     bs::seg_plane_t<Cloud, VecD, VecI, VecC> h(cloud, normal, neigh, 15);
     auto planes = h.get_planes();
+    // The reference never seeds rand() (my_function.cpp:269), i.e. it draws from
+    // glibc's seed-1 stream; the HIP runtime consumes rand() values during
+    // initialisation, so restore that stream before drawing the colours.
+    srand(1);
     h.set_plane_color(planes);
     fprintf(stderr, "tmc3: %zu points, %zu planes\n", n, planes.size());
   } catch (const std::exception& e) {
