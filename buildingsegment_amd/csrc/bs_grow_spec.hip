@@ -46,6 +46,7 @@ namespace {
 
 constexpr int32_t INF = 0x7fffffff;
 constexpr int MAX_WAVES = 1024;  // plane attempts grown concurrently per round
+constexpr int MAX_PENDING = 4096;  // finished planes waiting for earlier attempts
 
 enum : int32_t { ST_NONE = 0, ST_DONE = 1, ST_FAILED0 = 2, ST_NOMEM = 3, ST_WATCHDOG = 4, ST_STOLEN = 5 };
 
@@ -203,81 +204,160 @@ __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int32
 }
 
 // ---- (b) speculative plane growth: one wavefront per candidate seed -------------
-// Step engine: every lane that gathers a neighbour also prefetches that
-// neighbour's own neighbour row, so the next Broad() call (first accepted
-// child) starts from registers, and the other accepted children are pushed on
-// the LIFO together with their rows (slot 0 of a row is never read by Broad,
-// :224, so it carries the point id).  One dependent HBM round trip per step
-// instead of three (pop -> row -> gather).
+// Data layout for a latency-bound gather: one record per point holding
+// everything a Broad() test needs plus the point's own neighbour row, so a
+// candidate costs ONE cache line:
+//   int4 q0 = x, y, z, owner (tentative owner of this round)
+//   int4 q1 = normal.x, normal.y            (f64 bit patterns)
+//   int4 q2 = normal.z, tag, pad            (tag: in-flight claim, atomics)
+//   int4 q3 = pad
+//   int4 q4.. = neighbour row (K ints; slot 0 unused by Broad, :224)
+// 128 B per point at K <= 16, 192 B at K <= 32.
+template <int KC>
+struct RecLayout {
+  static constexpr int QUADS = 4 + KC / 4;  // int4 per record
+};
+
+__device__ inline int32_t* rec_tag(int4* rec, int quads, int64_t i)
+{
+  return reinterpret_cast<int32_t*>(rec + i * quads + 2) + 2;
+}
+
+template <int KC>
+__global__ void build_records_kernel(SpecArgs a, int4* __restrict__ rec)
+{
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= a.n)
+    return;
+  constexpr int Q = RecLayout<KC>::QUADS;
+  int4* r = rec + i * Q;
+  const double nx = a.normals[3 * i], ny = a.normals[3 * i + 1], nz = a.normals[3 * i + 2];
+  r[0] = make_int4(a.xyz[3 * i], a.xyz[3 * i + 1], a.xyz[3 * i + 2], INF);
+  r[1] = make_int4(__double2loint(nx), __double2hiint(nx), __double2loint(ny), __double2hiint(ny));
+  r[2] = make_int4(__double2loint(nz), __double2hiint(nz), INF, 0);
+  r[3] = make_int4(0, 0, 0, 0);
+  int row[KC];
+#pragma unroll
+  for (int j = 0; j < KC; j++)
+    row[j] = j < a.K ? a.neigh[i * a.K + j] : 0;
+#pragma unroll
+  for (int j = 0; j < KC; j += 4)
+    r[4 + j / 4] = make_int4(row[j], row[j + 1], row[j + 2], row[j + 3]);
+}
+
+// per round: owner snapshot in, claims cleared
+__global__ void refresh_records_kernel(const int32_t* __restrict__ omega, int4* __restrict__ rec, int quads, int64_t n)
+{
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  reinterpret_cast<int32_t*>(rec + i * quads)[3] = omega[i];
+  *rec_tag(rec, quads, i) = INF;
+}
+
+constexpr int LDS_STACK = 256;  // LIFO entries (with rows) kept in LDS
+
+// Step engine.
+//  * Every lane that gathers a neighbour gets that neighbour's own row with it
+//    (same cache line), so the next Broad() call (first accepted child) starts
+//    from registers; the other accepted children go on the LIFO with their rows
+//    (id in slot 0).  The top LDS_STACK entries of the LIFO live in LDS
+//    (write-through to the HBM slab): a pop is an LDS read.
+//  * Multi-pop: 64 % of all Broad() calls accept nothing, in long runs (DFS
+//    backtracking).  A call that accepts nothing changes neither the plane
+//    state nor any label, so the NEXT pending call sees exactly the same world:
+//    the wave evaluates NG = 64 / KC pending calls at once (lane group g = the
+//    g-th next call), consumes the leading run of empty ones, expands the first
+//    non-empty one and leaves the rest on the LIFO.  Claims (atomics) are only
+//    issued for the call that is really expanded.
 template <int KC>
 __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t* __restrict__ cand, int ncand,
-                                                       const int32_t* __restrict__ omega, int32_t* tag, Pool pool,
+                                                       int4* rec, int32_t* dead, Pool pool,
                                                        PlaneOut* __restrict__ out, int64_t step_cap)
 {
+  __shared__ __attribute__((aligned(16))) int lds_stack[LDS_STACK * KC];
+  constexpr int Q = RecLayout<KC>::QUADS;
+  constexpr int NG = 64 / KC;
   const int w = blockIdx.x;
   if (w >= ncand)
     return;
   const int lane = threadIdx.x;
+  const int g = lane / KC, j = lane % KC;
+  const unsigned long long gmask0 = (KC == 32) ? 0xffffffffull : 0xffffull;
   const int K = a.K, nc = K - 1;
-  const bool vec = a.vec != 0;
+  const bool act = j < nc;
   const int32_t seed = cand[w];
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
-  int64_t ln = 1, sp = 0, logn = 0, steps = 0;
+  int64_t ln = 1, sp = 0, lds_lo = 0, logn = 0, steps = 0, iters = 0;
   int status = ST_DONE;
-  double cnx = a.normals[3 * (int64_t)seed], cny = a.normals[3 * (int64_t)seed + 1],
-         cnz = a.normals[3 * (int64_t)seed + 2];
-  int ccx = a.xyz[3 * (int64_t)seed], ccy = a.xyz[3 * (int64_t)seed + 1], ccz = a.xyz[3 * (int64_t)seed + 2];
+  const int4* srec = rec + (int64_t)seed * Q;
+  const int4 s0 = srec[0], s1 = srec[1], s2 = srec[2];
+  double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z), cnz = __hiloint2double(s2.y, s2.x);
+  int ccx = s0.x, ccy = s0.y, ccz = s0.z;
   double Sx = 0.0 + cnx, Sy = 0.0 + cny, Sz = 0.0 + cnz;
   uint32_t Cx = (uint32_t)ccx, Cy = (uint32_t)ccy, Cz = (uint32_t)ccz;
-  if (!slab_ensure(pool, list, 0, 2048, lane) || !slab_ensure(pool, stack, 0, 256 * (int64_t)K, lane) ||
+  if (!slab_ensure(pool, list, 0, 2048, lane) || !slab_ensure(pool, stack, 0, 256 * (int64_t)KC, lane) ||
       !slab_ensure(pool, log, 0, 2048, lane)) {
     status = ST_NOMEM;
   } else {
     if (lane == 0)
       pool.base[list.off] = seed;
-    const bool act = lane < nc;
-    int cand_id = act ? a.neigh[(int64_t)seed * K + lane + 1] : 0;
+    // the call that continues from registers (first accepted child); at the
+    // start it is Broad(seed, 0)
+    bool have_child = true;
+    int child_cand = (g == 0 && act) ? reinterpret_cast<const int32_t*>(srec + 4)[j + 1] : 0;
     bool depth0 = true;
     for (;;) {
-      if (++steps > step_cap) {
+      if (!have_child && sp == 0)
+        break;
+      if (++iters > step_cap) {
         status = ST_WATCHDOG;
         break;
       }
+      // ---- which pending call does my lane group evaluate? ----
+      const int fs = have_child ? 1 : 0;              // first stack-fed group
+      const int64_t e = sp - 1 - (int64_t)(g - fs);   // LIFO entry of a stack-fed group
+      const bool is_child = have_child && g == 0;
+      const bool valid = is_child || (g >= fs && e >= 0);
+      const int ngv = fs + (int)((sp < (int64_t)(NG - fs)) ? sp : (int64_t)(NG - fs));  // valid groups
+      int cand_id = 0;
+      if (valid && act) {
+        if (is_child)
+          cand_id = child_cand;
+        else if (e >= lds_lo)
+          cand_id = lds_stack[(e & (LDS_STACK - 1)) * KC + j + 1];
+        else
+          cand_id = ld_i32(pool.base + stack.off + e * KC + j + 1);
+      }
+      const int killed = ld_i32(dead + seed);  // an earlier plane took one of my points: I am invalid
       int own = 0, tg = INF, px = 0, py = 0, pz = 0;
       double mx = 0, my = 0, mz = 0;
       int row[KC];
 #pragma unroll
-      for (int j = 0; j < KC; j++)
-        row[j] = 0;
-      if (act) {
-        own = omega[cand_id];
-        tg = ld_i32(tag + cand_id);
-        px = a.xyz[3 * (int64_t)cand_id];
-        py = a.xyz[3 * (int64_t)cand_id + 1];
-        pz = a.xyz[3 * (int64_t)cand_id + 2];
-        mx = a.normals[3 * (int64_t)cand_id];
-        my = a.normals[3 * (int64_t)cand_id + 1];
-        mz = a.normals[3 * (int64_t)cand_id + 2];
-        const int32_t* rp = a.neigh + (int64_t)cand_id * K;
-        if (vec) {
+      for (int t = 0; t < KC; t++)
+        row[t] = 0;
+      if (valid && act) {
+        const int4* r = rec + (int64_t)cand_id * Q;
+        const int4 q0 = r[0], q1 = r[1], q2 = r[2];
+        tg = ld_i32(reinterpret_cast<const int32_t*>(r + 2) + 2);
+        px = q0.x;
+        py = q0.y;
+        pz = q0.z;
+        own = q0.w;
+        mx = __hiloint2double(q1.y, q1.x);
+        my = __hiloint2double(q1.w, q1.z);
+        mz = __hiloint2double(q2.y, q2.x);
 #pragma unroll
-          for (int j = 0; j < KC; j += 4)
-            if (j < K) {
-              const int4 v = *reinterpret_cast<const int4*>(rp + j);
-              row[j] = v.x;
-              row[j + 1] = v.y;
-              row[j + 2] = v.z;
-              row[j + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-          for (int j = 1; j < KC; j++)
-            if (j < K)
-              row[j] = rp[j];
+        for (int t = 0; t < KC; t += 4) {
+          const int4 v = r[4 + t / 4];
+          row[t] = v.x;
+          row[t + 1] = v.y;
+          row[t + 2] = v.z;
+          row[t + 3] = v.w;
         }
       }
       bool geo = false;
-      if (act && tg != seed) {  // tg == seed: already labelled by this plane
+      if (valid && act && tg != seed) {  // tg == seed: already labelled by this plane
         const int dx = (int)((uint32_t)px - (uint32_t)ccx);
         const int dy = (int)((uint32_t)py - (uint32_t)ccy);
         const int dz = (int)((uint32_t)pz - (uint32_t)ccz);
@@ -285,94 +365,147 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         const double dt = cnx * mx + cny * my + cnz * mz;
         geo = dist <= a.th && dt >= a.cos_th;
       }
-      // taken by a sequentially earlier attempt?  (final, tentative, or in flight)
-      const bool taken = geo && (own < seed || tg < seed);
-      bool ok = geo && !taken;
-      if (ok) {
-        const int old = atomicMin(tag + cand_id, seed);
-        if (old < seed)
-          ok = false;  // lost the race to an earlier plane: now taken
+      if (killed) {
+        status = ST_STOLEN;
+        break;
       }
-      const bool assume = geo && !ok && !(own < a.F);  // relied on a non-final owner: log it
-      const unsigned long long am = __ballot(ok);
-      const unsigned long long lm = __ballot(assume);
-      const int cnt = __popcll(am);
+      // side-effect free classification
+      bool assume = geo && own < seed && !(own < a.F);  // kept by an earlier, not yet final attempt
+      const bool contender = geo && !(own < seed);
+      const unsigned long long cm = __ballot(contender);
+      // ---- walk the pending calls in order: consume empty ones, stop at the first that accepts ----
+      unsigned long long am = 0;
+      int gstar = -1;
+      bool ok = false;
+      for (int gg = 0; gg < ngv; gg++) {
+        const unsigned long long gm = gmask0 << (gg * KC);
+        if (cm & gm) {
+          // Claim protocol for call gg.  tag[p] = seed of the in-flight plane
+          // holding p.  A sequentially earlier plane always wins (atomicMin); a
+          // plane that loses a point it had accepted is marked dead, and points
+          // held by dead planes can be reclaimed.  Every "taken" decision that
+          // rests on a non-final owner is logged and re-checked after the round.
+          if (g == gg && contender) {
+            int32_t* tp = rec_tag(rec, Q, cand_id);
+            int cur_tag = tg;
+            bool mine = false;
+            for (int tries = 0; tries < 8 && !ok && !assume && !mine; tries++) {
+              if (cur_tag < seed) {            // an earlier in-flight plane holds it ...
+                if (ld_i32(dead + cur_tag)) {  // ... which is already invalid: reclaim
+                  const int old = atomicCAS(tp, cur_tag, seed);
+                  if (old == cur_tag)
+                    ok = true;
+                  else
+                    cur_tag = old;
+                } else {
+                  assume = true;
+                }
+              } else if (cur_tag == seed) {
+                mine = true;
+              } else {  // free, or held by a later plane
+                const int old = atomicMin(tp, seed);
+                if (old < seed) {
+                  cur_tag = old;  // lost the race
+                } else if (old == seed) {
+                  mine = true;
+                } else {
+                  if (old != INF)
+                    dead[old] = 1;  // took it from a later plane: that plane is invalid
+                  ok = true;
+                }
+              }
+            }
+            if (!ok && !mine)
+              assume = true;
+          }
+          am = __ballot(ok);
+          if (am) {
+            gstar = gg;
+            break;
+          }
+        }
+      }
+      const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed
+      steps += last + 1;
+      // assumptions made by consumed calls
+      const unsigned long long lm = __ballot(assume && g <= last);
       const int lcnt = __popcll(lm);
       if (lcnt) {
         if (!slab_ensure(pool, log, logn, logn + lcnt, lane)) {
           status = ST_NOMEM;
           break;
         }
-        if (assume)
+        if (assume && g <= last)
           pool.base[log.off + logn + __popcll(lm & ((1ull << lane) - 1ull))] = cand_id;
         logn += lcnt;
       }
+      const int cnt = __popcll(am);
       if (depth0 && cnt < nc) {
         status = ST_FAILED0;  // under speculation this seed is (currently) an orphan maker
         break;
       }
       depth0 = false;
-      if (cnt) {
-        if (!slab_ensure(pool, list, ln, ln + cnt, lane) ||
-            !slab_ensure(pool, stack, sp * K, (sp + cnt) * K, lane)) {
-          status = ST_NOMEM;
-          break;
-        }
-        const int rank = __popcll(am & ((1ull << lane) - 1ull));
-        if (ok)
-          pool.base[list.off + ln + rank] = cand_id;
-        unsigned long long mm = am;
-        while (mm) {
-          const int l = __ffsll(mm) - 1;
-          mm &= mm - 1;
-          Sx += readlane_f64(mx, l);
-          Sy += readlane_f64(my, l);
-          Sz += readlane_f64(mz, l);
-          Cx += (uint32_t)readlane_i32(px, l);
-          Cy += (uint32_t)readlane_i32(py, l);
-          Cz += (uint32_t)readlane_i32(pz, l);
-        }
-        ln += cnt;
-        const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
-        cnx = Sx / nrm;
-        cny = Sy / nrm;
-        cnz = Sz / nrm;
-        const uint64_t dn = (uint64_t)ln;
-        ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);
-        ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
-        ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
-        // children 2..cnt go on the LIFO (reversed) with their rows; id in slot 0
-        if (ok && rank > 0) {
-          int32_t* slot = pool.base + stack.off + (sp + (cnt - 1 - rank)) * K;
-          row[0] = cand_id;
-          if (vec) {
-#pragma unroll
-            for (int j = 0; j < KC; j += 4)
-              if (j < K)
-                *reinterpret_cast<int4*>(slot + j) = make_int4(row[j], row[j + 1], row[j + 2], row[j + 3]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < KC; j++)
-              if (j < K)
-                slot[j] = row[j];
-          }
-        }
-        sp += cnt - 1;
-        // first child continues from registers: lane l takes row_f[l + 1]
-        const int f = __ffsll(am) - 1;
-        int nxt = 0;
-#pragma unroll
-        for (int j = 1; j < KC; j++) {
-          const int t = readlane_i32(row[j], f);
-          nxt = (lane == j - 1) ? t : nxt;
-        }
-        cand_id = nxt;
-      } else {
-        if (sp == 0)
-          break;
-        sp--;
-        cand_id = act ? ld_i32(pool.base + stack.off + sp * K + lane + 1) : 0;
+      // pops: every consumed stack-fed call (the expanded one included)
+      sp -= (last + 1 - fs);
+      have_child = false;
+      if (sp < lds_lo)
+        lds_lo = sp;  // entries below are only in HBM; new pushes land in LDS again
+      if (gstar < 0)
+        continue;
+      // ---- expand call gstar: :231-255 ----
+      if (!slab_ensure(pool, list, ln, ln + cnt, lane) || !slab_ensure(pool, stack, sp * KC, (sp + cnt) * KC, lane)) {
+        status = ST_NOMEM;
+        break;
       }
+      const int rank = __popcll(am & ((1ull << lane) - 1ull));
+      if (ok)
+        pool.base[list.off + ln + rank] = cand_id;
+      unsigned long long mm = am;
+      while (mm) {
+        const int l = __ffsll(mm) - 1;
+        mm &= mm - 1;
+        Sx += readlane_f64(mx, l);
+        Sy += readlane_f64(my, l);
+        Sz += readlane_f64(mz, l);
+        Cx += (uint32_t)readlane_i32(px, l);
+        Cy += (uint32_t)readlane_i32(py, l);
+        Cz += (uint32_t)readlane_i32(pz, l);
+      }
+      ln += cnt;
+      const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+      cnx = Sx / nrm;
+      cny = Sy / nrm;
+      cnz = Sz / nrm;
+      const uint64_t dn = (uint64_t)ln;
+      ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);
+      ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
+      ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
+      // children 2..cnt go on the LIFO (reversed) with their rows; id in slot 0
+      if (ok && rank > 0) {
+        const int64_t pe = sp + (cnt - 1 - rank);
+        int4* slot = reinterpret_cast<int4*>(pool.base + stack.off + pe * KC);
+        int4* lslot = reinterpret_cast<int4*>(lds_stack + (pe & (LDS_STACK - 1)) * KC);
+        row[0] = cand_id;
+#pragma unroll
+        for (int t = 0; t < KC; t += 4) {
+          const int4 v = make_int4(row[t], row[t + 1], row[t + 2], row[t + 3]);
+          slot[t / 4] = v;
+          lslot[t / 4] = v;
+        }
+      }
+      sp += cnt - 1;
+      if (sp - lds_lo > LDS_STACK)
+        lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)
+      // first child continues from registers: lane j of group 0 takes row_f[j + 1]
+      const int f = __ffsll(am) - 1;
+      int nxt = 0;
+#pragma unroll
+      for (int t = 1; t < KC; t++) {
+        const int v = readlane_i32(row[t], f);
+        nxt = (lane == t - 1) ? v : nxt;
+      }
+      child_cand = nxt;
+      have_child = true;
     }
   }
   if (lane == 0) {
@@ -399,7 +532,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
 
 // every accepted point must still carry this plane's claim
 __global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
-                                                       const int32_t* __restrict__ tag, uint8_t* ps)
+                                                       int4* rec, int quads, uint8_t* ps)
 {
   const int w = blockIdx.x;
   if (w >= ncand || out[w].status != ST_DONE)
@@ -407,7 +540,7 @@ __global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand,
   const PlaneOut o = out[w];
   bool bad = false;
   for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64)
-    bad = bad || tag[pool[o.list_off + t]] != o.seed;
+    bad = bad || *rec_tag(rec, quads, pool[o.list_off + t]) != o.seed;
   if (__ballot(bad)) {
     if (threadIdx.x == 0)
       out[w].status = ST_STOLEN;
@@ -451,6 +584,13 @@ __global__ __launch_bounds__(64) void validate2_kernel(PlaneOut* out, int ncand,
   const unsigned long long b = __ballot(bad);
   if (threadIdx.x == 0)
     out[w].consistent = b ? 0 : 1;
+}
+
+__global__ void mark_ps_kernel(const PlaneOut* __restrict__ arr, int cnt, uint8_t* ps)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt && arr[i].status == ST_DONE)
+    ps[arr[i].seed] = 1;
 }
 
 __global__ void finalize_owner_kernel(const int32_t* __restrict__ omega, int32_t first_bad, int64_t n,
@@ -543,14 +683,14 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;
   // round pool: lists + stacks + logs of every concurrent attempt
   const unsigned long long pool_cap =
-      (unsigned long long)std::max<int64_t>(std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * K) * 2 * MAX_WAVES);
+      (unsigned long long)std::max<int64_t>(std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * 32) * 2 * MAX_WAVES);
   BS_HIP(ctx, ctx->rg_list.reserve(sizeof(int32_t) * list_cap));
   BS_HIP(ctx, ctx->rg_planes.reserve(sizeof(PlaneRec) * planes_cap));
   BS_HIP(ctx, ctx->rg_stats.reserve(sizeof(GrowStats)));
   // aux layout (int32 units): misc[1024] | hmask | owner_final | bufA | bufB | base | tag | cand | seeds |
   //                            flags(u8) | ps(u8) | PlaneOut[MAX_WAVES]
-  const size_t aux_bytes = sizeof(int32_t) * (size_t)(7 * n + planes_cap + 1024 + 64) + (size_t)2 * n + 4096 +
-                           sizeof(PlaneOut) * MAX_WAVES;
+  const size_t aux_bytes = sizeof(int32_t) * (size_t)(8 * n + planes_cap + 1024 + 64) + (size_t)2 * n + 4096 +
+                           sizeof(PlaneOut) * (MAX_WAVES + MAX_PENDING);
   BS_HIP(ctx, ctx->rg_aux.reserve(aux_bytes));
   BS_HIP(ctx, ctx->rg_stack.reserve(sizeof(int32_t) * pool_cap));
   int32_t* aux = ctx->rg_aux.as<int32_t>();
@@ -561,11 +701,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int32_t* bufB = aux + 1024 + 3 * n;
   int32_t* base = aux + 1024 + 4 * n;
   int32_t* tag = aux + 1024 + 5 * n;
-  int32_t* d_cand = aux + 1024 + 6 * n;  // select output (n entries)
-  int32_t* d_seeds = aux + 1024 + 7 * n;  // committed seeds (planes_cap)
-  uint8_t* flags = (uint8_t*)(aux + 1024 + 7 * n + planes_cap + 64);
+  int32_t* dead = aux + 1024 + 6 * n;    // directly after tag
+  int32_t* d_cand = aux + 1024 + 7 * n;  // select output (n entries)
+  int32_t* d_seeds = aux + 1024 + 8 * n;  // committed seeds (planes_cap)
+  uint8_t* flags = (uint8_t*)(aux + 1024 + 8 * n + planes_cap + 64);
   uint8_t* ps = flags + n;
   PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(ps + n) + 255) & ~(uintptr_t)255);
+  PlaneOut* d_pend = d_out + MAX_WAVES;
   unsigned long long* d_pool_top = (unsigned long long*)(d_misc + 16);
   Pool pool = {ctx->rg_stack.as<int32_t>(), d_pool_top, pool_cap};
 
@@ -581,13 +723,30 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   a.F = 0;
   a.vec = ((K & 3) == 0 && ((uintptr_t)d_neigh & 15) == 0) ? 1 : 0;
 
+  const int KC = K <= 16 ? 16 : 32;
+  const int quads = 4 + KC / 4;
+  BS_HIP(ctx, ctx->rg_rec.reserve(sizeof(int4) * (size_t)quads * n));
+  int4* rec = ctx->rg_rec.as<int4>();
+  if (KC == 16)
+    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, rec);
+  else
+    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec);
   static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, hmask);
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, INF);
   BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
 
+  // persistent store for planes that finished consistently but cannot be
+  // finalised yet (an earlier attempt is still open): kept across rounds and
+  // re-validated instead of being re-grown
+  const int64_t pstore_cap = 6 * n + 65536;
+  BS_HIP(ctx, ctx->rg_pstore.reserve(sizeof(int32_t) * pstore_cap));
+  int32_t* pstore = ctx->rg_pstore.as<int32_t>();
+  int64_t pstore_top = 0;
+  std::vector<PlaneOut> pending;
+
   std::vector<PlaneRec> recs;
   std::vector<int32_t> seeds;
-  std::vector<PlaneOut> h_out(MAX_WAVES);
+  std::vector<PlaneOut> h_out(MAX_WAVES), h_pend;
   int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0, passes = 0;
   int32_t F = 0;
   size_t sel_tmp = 0;
@@ -596,16 +755,49 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, sel_tmp, it, flags, d_cand, d_misc + 1, (int)n, st));
     BS_HIP(ctx, ctx->cub_tmp.reserve(sel_tmp));
   }
+  auto commit_plane = [&](const PlaneOut& o, const int32_t* src_pool) -> int {
+    attempts++;
+    if (!o.keep)
+      return BS_OK;  // rolled back: no trace
+    if (list_used + o.list_n > list_cap || (int64_t)recs.size() >= planes_cap)
+      return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): list pool overflow");
+    copy_list_kernel<<<nblk(o.list_n, 256), 256, 0, st>>>(src_pool, o.list_off, o.list_n,
+                                                          ctx->rg_list.as<int32_t>() + list_used);
+    PlaneRec r;
+    for (int c = 0; c < 3; c++) {
+      r.normal[c] = o.normal[c];
+      r.center[c] = o.center[c];
+    }
+    r.list_off = list_used;
+    r.list_n = o.list_n;
+    r.id = (int32_t)recs.size() + 1;
+    r.seed = o.seed;
+    r.pad = 0;
+    recs.push_back(r);
+    seeds.push_back(o.seed);
+    list_used += o.list_n;
+    largest = std::max<int64_t>(largest, o.list_n);
+    return BS_OK;
+  };
   int max_waves = MAX_WAVES;
   for (;;) {
     rounds++;
     a.F = F;
-    // tentative owners with every open attempt treated as an orphan maker
+    const int npend = (int)pending.size();
+    // owner base = finals + pending planes (their seeds are not orphan makers)
+    BS_HIP(ctx, hipMemcpyAsync(base, owner_final, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
+    BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
+    if (npend) {
+      BS_HIP(ctx, hipMemcpyAsync(d_pend, pending.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
+      mark_ps_kernel<<<nblk(npend, 256), 256, 0, st>>>(d_pend, npend, ps);
+      insert_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, base);
+    }
+    // tentative owners with every other open attempt treated as an orphan maker
     int32_t* omega = nullptr;
-    int rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, owner_final, bufA, bufB, d_misc, &omega, &passes);
+    int rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, base, bufA, bufB, d_misc, &omega, &passes);
     if (rc != BS_OK)
       return rc;
-    // lowest plane-attempt candidates
+    // lowest new plane-attempt candidates
     cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, flags, nullptr);
     {
       hipcub::CountingInputIterator<int32_t> it(0);
@@ -615,35 +807,42 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     int32_t ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
-    if (ncand_all == 0) {
+    if (ncand_all == 0 && npend == 0) {
       // no plane attempt left: the fixed point is the final owner array
       BS_HIP(ctx, hipMemcpyAsync(owner_final, omega, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
       break;
     }
     const int ncand = std::min<int>(ncand_all, max_waves);
-    // grow them concurrently
-    fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(tag, n, INF);
-    BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
-    if (K <= 16)
-      grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, omega, tag, pool, d_out, 512 * n + 4096);
-    else
-      grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, omega, tag, pool, d_out, 512 * n + 4096);
-    validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, tag, ps);
-    // owner base with the finished planes inserted, then the new fixed point
-    BS_HIP(ctx, hipMemcpyAsync(base, owner_final, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
-    insert_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base);
-    int32_t* omega2 = nullptr;
-    // omega lives in bufA/bufB; the second fixed point reuses them, so keep nothing from the first
-    rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, base, bufA, bufB, d_misc, &omega2, &passes);
-    if (rc != BS_OK)
-      return rc;
-    validate2_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, omega2, d_neigh, K);
+    int32_t* omega2 = omega;
+    if (ncand > 0) {
+      // grow them concurrently
+      refresh_records_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, rec, quads, n);
+      BS_HIP(ctx, hipMemsetAsync(dead, 0, sizeof(int32_t) * n, st));
+      BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
+      if (KC == 16)
+        grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
+      else
+        grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
+      validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, rec, quads, ps);
+      // insert the finished planes and recompute the fixed point
+      insert_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base);
+      rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, base, bufA, bufB, d_misc, &omega2, &passes);
+      if (rc != BS_OK)
+        return rc;
+      validate2_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, omega2, d_neigh, K);
+    }
+    if (npend)
+      validate2_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, omega2, d_neigh, K);
     int32_t inf = INF;
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 2, &inf, sizeof inf, hipMemcpyHostToDevice, st));
     cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega2, nullptr, d_misc + 2);
     int32_t new_min = INF;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
-    BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
+    if (ncand)
+      BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
+    h_pend.resize(npend);
+    if (npend)
+      BS_HIP(ctx, hipMemcpyAsync(h_pend.data(), d_pend, sizeof(PlaneOut) * npend, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
     // first attempt (by seed index) whose result is not established
     int32_t first_bad = new_min;
@@ -657,13 +856,16 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       if (w == 0 && o.status == ST_NOMEM)
         nomem_lowest = true;
     }
+    for (int w = 0; w < npend; w++)
+      if (!h_pend[w].consistent)
+        first_bad = std::min(first_bad, h_pend[w].seed);
     if (nomem_lowest) {
       if (max_waves == 1)
         return fail(ctx, BS_ERR_NOMEM, "region grow (speculative): round pool exhausted");
       max_waves = std::max(1, max_waves / 8);
     }
     if (getenv("BS_DEBUG")) {
-      int cnt[6] = {0, 0, 0, 0, 0, 0}, cons = 0;
+      int cnt[6] = {0, 0, 0, 0, 0, 0}, cons = 0, pcons = 0;
       int64_t maxsteps = 0, sumsteps = 0, maxlist = 0;
       for (int w = 0; w < ncand; w++) {
         cnt[h_out[w].status]++;
@@ -672,56 +874,66 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         sumsteps += h_out[w].steps;
         maxlist = std::max(maxlist, h_out[w].list_n);
       }
+      for (int w = 0; w < npend; w++)
+        pcons += h_pend[w].consistent;
       fprintf(stderr,
               "[bs] round %ld F=%d ncand_all=%d grown=%d done=%d (consistent %d) failed0=%d nomem=%d stolen=%d "
-              "first_bad=%d new_min=%d lowest=%d highest=%d maxsteps=%ld sumsteps=%ld maxlist=%ld passes=%ld\n",
+              "pending=%d (consistent %d) first_bad=%d new_min=%d maxsteps=%ld sumsteps=%ld maxlist=%ld passes=%ld\n",
               (long)rounds, F, ncand_all, ncand, cnt[ST_DONE], cons, cnt[ST_FAILED0], cnt[ST_NOMEM], cnt[ST_STOLEN],
-              first_bad, new_min, h_out[0].seed, h_out[ncand - 1].seed, (long)maxsteps, (long)sumsteps,
-              (long)maxlist, (long)passes);
+              npend, pcons, first_bad, new_min, (long)maxsteps, (long)sumsteps, (long)maxlist, (long)passes);
     }
-    // commit everything below first_bad, in seed order (cand is sorted)
-    int finals = 0;
-    for (int w = 0; w < ncand; w++) {
-      const PlaneOut& o = h_out[w];
-      if (o.seed >= first_bad)
-        break;
-      if (o.status != ST_DONE || !o.consistent)
-        continue;  // an orphan maker under the final owners (seed or a neighbour was taken)
-      finals++;
-      attempts++;
-      if (!o.keep)
-        continue;  // rolled back: no trace
-      if (list_used + o.list_n > list_cap || (int64_t)recs.size() >= planes_cap)
-        return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): list pool overflow");
-      copy_list_kernel<<<nblk(o.list_n, 256), 256, 0, st>>>(pool.base, o.list_off, o.list_n,
-                                                            ctx->rg_list.as<int32_t>() + list_used);
-      PlaneRec r;
-      for (int c = 0; c < 3; c++) {
-        r.normal[c] = o.normal[c];
-        r.center[c] = o.center[c];
+    // merge pending and new planes in seed order: below first_bad -> final,
+    // consistent ones above it stay pending, the rest is dropped
+    std::vector<PlaneOut> next_pending;
+    int finals = 0, dropped = 0;
+    {
+      int ip = 0, iw = 0;
+      while (ip < npend || iw < ncand) {
+        const bool take_p = (iw >= ncand) || (ip < npend && h_pend[ip].seed < h_out[iw].seed);
+        const PlaneOut& o = take_p ? h_pend[ip] : h_out[iw];
+        const int32_t* src = take_p ? pstore : pool.base;
+        if (take_p)
+          ip++;
+        else
+          iw++;
+        if (o.status != ST_DONE || !o.consistent) {
+          dropped += take_p ? 1 : 0;  // an invalidated pending plane re-enters as a candidate
+          continue;
+        }
+        if (o.seed < first_bad) {
+          finals++;
+          rc = commit_plane(o, src);
+          if (rc != BS_OK)
+            return rc;
+        } else if (take_p) {
+          next_pending.push_back(o);
+        } else if ((int)next_pending.size() < MAX_PENDING && pstore_top + o.list_n + o.log_n + 8 <= pstore_cap) {
+          PlaneOut q = o;
+          q.list_off = pstore_top;
+          copy_list_kernel<<<nblk(o.list_n, 256), 256, 0, st>>>(pool.base, o.list_off, o.list_n, pstore + q.list_off);
+          pstore_top += (o.list_n + 3) & ~(int64_t)3;
+          q.log_off = pstore_top;
+          if (o.log_n)
+            copy_list_kernel<<<nblk(o.log_n, 256), 256, 0, st>>>(pool.base, o.log_off, o.log_n, pstore + q.log_off);
+          pstore_top += (o.log_n + 3) & ~(int64_t)3;
+          next_pending.push_back(q);
+        }
       }
-      r.list_off = list_used;
-      r.list_n = o.list_n;
-      r.id = (int32_t)recs.size() + 1;
-      r.seed = o.seed;
-      r.pad = 0;
-      recs.push_back(r);
-      seeds.push_back(o.seed);
-      list_used += o.list_n;
-      largest = std::max<int64_t>(largest, o.list_n);
     }
+    pending.swap(next_pending);
+    if (pending.empty())
+      pstore_top = 0;
     if (first_bad == INF) {
       // no open plane attempt is left (an ungrown candidate would have shown up
-      // in new_min): every remaining attempt is an orphan maker and omega2 is
-      // their fixed point
+      // in new_min; every pending plane was consistent and has been committed):
+      // every remaining attempt is an orphan maker and omega2 is their fixed point
       BS_HIP(ctx, hipMemcpyAsync(owner_final, omega2, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
       break;
     }
     finalize_owner_kernel<<<nblk(n, 256), 256, 0, st>>>(omega2, first_bad, n, owner_final);
-    F = first_bad;
-    BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
-    if (finals == 0 && !nomem_lowest && first_bad <= h_out[0].seed)
+    if (finals == 0 && dropped == 0 && !nomem_lowest && first_bad <= F)
       return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): no progress");
+    F = first_bad;
     if (rounds > 4 * n + 16)
       return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): round limit");
   }
