@@ -290,6 +290,10 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
   int64_t ln = 1, sp = 0, lds_lo = 0, logn = 0, steps = 0, iters = 0;
   int status = ST_DONE;
+  // optimistic claims: the atomicMin of call i is only checked in call i+1,
+  // after the next gather has been issued (its latency hides the atomic's)
+  bool pend = false;
+  int pend_old = INF;
   const int4* srec = rec + (int64_t)seed * Q;
   const int4 s0 = srec[0], s1 = srec[1], s2 = srec[2];
   double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z), cnz = __hiloint2double(s2.y, s2.x);
@@ -365,7 +369,12 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         const double dt = cnx * mx + cny * my + cnz * mz;
         geo = dist <= a.th && dt >= a.cos_th;
       }
-      if (killed) {
+      // settle last call's optimistic claims
+      const bool lost = pend && pend_old <= seed;  // an earlier plane got there first (or a double claim)
+      if (pend && pend_old > seed && pend_old != INF)
+        dead[pend_old] = 1;  // took it from a later plane: that plane is invalid
+      pend = false;
+      if (killed || __ballot(lost)) {
         status = ST_STOLEN;
         break;
       }
@@ -402,17 +411,10 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
                 }
               } else if (cur_tag == seed) {
                 mine = true;
-              } else {  // free, or held by a later plane
-                const int old = atomicMin(tp, seed);
-                if (old < seed) {
-                  cur_tag = old;  // lost the race
-                } else if (old == seed) {
-                  mine = true;
-                } else {
-                  if (old != INF)
-                    dead[old] = 1;  // took it from a later plane: that plane is invalid
-                  ok = true;
-                }
+              } else {  // free, or held by a later plane: claim, verify next call
+                pend_old = atomicMin(tp, seed);
+                pend = true;
+                ok = true;
               }
             }
             if (!ok && !mine)
@@ -507,6 +509,14 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       child_cand = nxt;
       have_child = true;
     }
+  }
+  // claims of the very last call
+  if (status == ST_DONE) {
+    const bool lost = pend && pend_old <= seed;
+    if (pend && pend_old > seed && pend_old != INF)
+      dead[pend_old] = 1;
+    if (__ballot(lost))
+      status = ST_STOLEN;
   }
   if (lane == 0) {
     PlaneOut o;
@@ -700,7 +710,6 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int32_t* bufA = aux + 1024 + 2 * n;
   int32_t* bufB = aux + 1024 + 3 * n;
   int32_t* base = aux + 1024 + 4 * n;
-  int32_t* tag = aux + 1024 + 5 * n;
   int32_t* dead = aux + 1024 + 6 * n;    // directly after tag
   int32_t* d_cand = aux + 1024 + 7 * n;  // select output (n entries)
   int32_t* d_seeds = aux + 1024 + 8 * n;  // committed seeds (planes_cap)
