@@ -45,7 +45,7 @@ namespace bs {
 namespace {
 
 constexpr int32_t INF = 0x7fffffff;
-constexpr int MAX_WAVES = 1024;  // plane attempts grown concurrently per round
+constexpr int MAX_WAVES = 4096;  // upper bound of plane attempts grown concurrently per round
 constexpr int MAX_PENDING = 4096;  // finished planes waiting for earlier attempts
 
 enum : int32_t { ST_NONE = 0, ST_DONE = 1, ST_FAILED0 = 2, ST_NOMEM = 3, ST_WATCHDOG = 4, ST_STOLEN = 5 };
@@ -788,7 +788,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     largest = std::max<int64_t>(largest, o.list_n);
     return BS_OK;
   };
-  int max_waves = MAX_WAVES;
+  int max_waves = 2048;
+  int32_t* reuse_omega = nullptr;
+  if (const char* e = getenv("BS_MAX_WAVES"))
+    max_waves = std::max(1, std::min(MAX_WAVES, atoi(e)));
   for (;;) {
     rounds++;
     a.F = F;
@@ -801,11 +804,18 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       mark_ps_kernel<<<nblk(npend, 256), 256, 0, st>>>(d_pend, npend, ps);
       insert_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, base);
     }
-    // tentative owners with every other open attempt treated as an orphan maker
+    // tentative owners with every other open attempt treated as an orphan maker.
+    // When the previous round dropped no plane, its closing fixed point was
+    // computed over exactly this base and plane-seed set: reuse it.
     int32_t* omega = nullptr;
-    int rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, base, bufA, bufB, d_misc, &omega, &passes);
-    if (rc != BS_OK)
-      return rc;
+    int rc = BS_OK;
+    if (reuse_omega) {
+      omega = reuse_omega;
+    } else {
+      rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, base, bufA, bufB, d_misc, &omega, &passes);
+      if (rc != BS_OK)
+        return rc;
+    }
     // lowest new plane-attempt candidates
     cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, flags, nullptr);
     {
@@ -932,6 +942,25 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     pending.swap(next_pending);
     if (pending.empty())
       pstore_top = 0;
+    {
+      // every inserted plane stays inserted (as final or pending) iff none was invalid or lost
+      bool all_kept = dropped == 0;
+      for (int w = 0; w < ncand && all_kept; w++)
+        if (h_out[w].status == ST_DONE && !h_out[w].consistent)
+          all_kept = false;
+      int64_t kept = 0, done = 0;
+      for (int w = 0; w < ncand; w++)
+        done += h_out[w].status == ST_DONE && h_out[w].seed >= first_bad;
+      for (const PlaneOut& q : pending)
+        kept += 1;
+      // (a consistent new plane above first_bad that did not fit into the pending store is lost)
+      int64_t old_above = 0;
+      for (int w = 0; w < npend; w++)
+        old_above += h_pend[w].seed >= first_bad;
+      if (kept != done + old_above)
+        all_kept = false;
+      reuse_omega = all_kept ? omega2 : nullptr;
+    }
     if (first_bad == INF) {
       // no open plane attempt is left (an ungrown candidate would have shown up
       // in new_min; every pending plane was consistent and has been committed):
