@@ -114,6 +114,9 @@ struct bs_ctx {
   bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec;
   int64_t rg_n = 0;
   bool rg_valid = false;
+  // cell-sorted order of the last grid build (vals_out): spatially coherent iteration for gathers
+  int64_t order_n = 0;
+  const int32_t* order_xyz = nullptr;
 };
 
 namespace bs {

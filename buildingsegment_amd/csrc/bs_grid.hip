@@ -38,12 +38,25 @@ __global__ void bbox_kernel(const int32_t* __restrict__ xyz, int64_t n, int32_t*
       mx[a] = max(mx[a], __shfl_xor(mx[a], o));
     }
   }
+  __shared__ int smn[3][4], smx[3][4];
+  const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      atomicMin(&mnmx[a], mn[a]);
-      atomicMax(&mnmx[3 + a], mx[a]);
+      smn[a][wv] = mn[a];
+      smx[a][wv] = mx[a];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    int m0 = smn[a][0], m1 = smx[a][0];
+    for (int t = 1; t < (int)(blockDim.x >> 6); t++) {
+      m0 = min(m0, smn[a][t]);
+      m1 = max(m1, smx[a][t]);
+    }
+    atomicMin(&mnmx[a], m0);
+    atomicMax(&mnmx[3 + a], m1);
   }
 }
 
@@ -63,11 +76,22 @@ __global__ void cellkey_kernel(const int32_t* __restrict__ xyz, int64_t n, int m
 
 __global__ void count_heads_kernel(const uint64_t* __restrict__ keys, int64_t n, unsigned long long* cnt)
 {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-  unsigned long long b = __ballot(head);
-  if ((threadIdx.x & 63) == 0 && b)
-    atomicAdd(cnt, (unsigned long long)__popcll(b));
+  unsigned int local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    local += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1)
+    local += __shfl_xor(local, o);
+  __shared__ unsigned int part[4];
+  if ((threadIdx.x & 63) == 0)
+    part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++)
+      t += part[k];
+    if (t)
+      atomicAdd(cnt, (unsigned long long)t);
+  }
 }
 
 __global__ void table_clear_kernel(CellEntry* t, uint32_t size)
@@ -133,7 +157,7 @@ static int count_cells(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const int m
   BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tb, kin, kout, (int)n, 0, 63, st));
   unsigned long long* cnt = ctx->misc.as<unsigned long long>() + 8;
   BS_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
-  count_heads_kernel<<<grid_blocks(n, 256), 256, 0, st>>>(kout, n, cnt);
+  count_heads_kernel<<<std::min(grid_blocks(n, 256), 1024), 256, 0, st>>>(kout, n, cnt);
   unsigned long long h = 0;
   BS_HIP(ctx, hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, st));
   BS_HIP(ctx, hipStreamSynchronize(st));
@@ -157,7 +181,7 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
   int32_t init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
   int32_t* d_mnmx = ctx->misc.as<int32_t>();
   BS_HIP(ctx, hipMemcpyAsync(d_mnmx, init, sizeof init, hipMemcpyHostToDevice, st));
-  bbox_kernel<<<std::min(grid_blocks(n, 256), 2048), 256, 0, st>>>(d_xyz, n, d_mnmx);
+  bbox_kernel<<<std::min(grid_blocks(n, 256), 512), 256, 0, st>>>(d_xyz, n, d_mnmx);
   int32_t bb[6];
   BS_HIP(ctx, hipMemcpyAsync(bb, d_mnmx, sizeof bb, hipMemcpyDeviceToHost, st));
   BS_HIP(ctx, hipStreamSynchronize(st));
@@ -253,6 +277,8 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
   out->spts = ctx->spts.as<int4>();
   out->slocal = vout;
   out->n = n;
+  ctx->order_n = n;  // vals_out holds the cell-sorted order of this cloud
+  ctx->order_xyz = d_xyz;
   return BS_OK;
 }
 

@@ -133,11 +133,14 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int64_t used, int6
 }
 
 // ---- (a) static depth-0 mask ------------------------------------------------
-__global__ void static_mask_kernel(SpecArgs a, uint32_t* __restrict__ hmask)
+// order (nullable): a spatially coherent permutation (the grid's cell-sorted
+// order), so that the neighbour gathers of adjacent threads share cache lines
+__global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order, uint32_t* __restrict__ hmask)
 {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= a.n)
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= a.n)
     return;
+  const int64_t i = order ? order[s] : s;
   const double cnx = a.normals[3 * i], cny = a.normals[3 * i + 1], cnz = a.normals[3 * i + 2];
   const int ccx = a.xyz[3 * i], ccy = a.xyz[3 * i + 1], ccz = a.xyz[3 * i + 2];
   uint32_t m = 0;
@@ -740,7 +743,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, rec);
   else
     build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec);
-  static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, hmask);
+  const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
+  static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, order, hmask);
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, INF);
   BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
 
