@@ -196,3 +196,74 @@ def test_halo_slab_form_matches_global_result(gpu_ctx, oracle):
                 assert np.array_equal(neigh, ng[own_idx]) and np.array_equal(normals, nr[own_idx])
             else:
                 assert unc > 0
+
+
+# ---- stress of the speculative scheduler (rg_mode 2) against the oracle ------------
+
+def _noisy_walls(n_per, seed, noise, shuffle=True):
+    rng = np.random.default_rng(seed)
+    m = int(np.sqrt(n_per))
+    u, v = np.meshgrid(np.arange(m) * 40, np.arange(m) * 40, indexing="ij")
+    u = u.ravel() + rng.integers(-10, 11, m * m)
+    v = v.ravel() + rng.integers(-10, 11, m * m)
+    w = rng.integers(-30, 31, m * m)
+    faces = [np.stack([u, v, w], 1), np.stack([u, w, v + 100], 1), np.stack([w, u + 100, v + 100], 1)]
+    tn = [np.array([0, 0, 1.0]), np.array([0, 1.0, 0]), np.array([1.0, 0, 0])]
+    xyz = np.concatenate(faces).astype(np.int64)
+    nrm = np.concatenate([np.tile(t, (m * m, 1)) for t in tn]) + rng.normal(0, noise, (3 * m * m, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[nrm[:, 2] < 0] *= -1
+    if shuffle:
+        perm = rng.permutation(len(xyz))
+        xyz, nrm = xyz[perm], nrm[perm]
+    xyz -= xyz.min(0)
+    return xyz.astype(np.int32), np.ascontiguousarray(nrm)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_per=20000, seed=1, noise=0.05, k=15, th_point_count=400),
+    dict(n_per=20000, seed=2, noise=0.25, k=15, th_point_count=400),   # orphans dominate
+    dict(n_per=12000, seed=3, noise=0.15, k=8, th_point_count=20),     # many tiny planes and roll-backs
+    dict(n_per=12000, seed=4, noise=0.10, k=24, th_point_count=0),     # every grown plane commits
+    dict(n_per=30000, seed=5, noise=0.02, k=16, th_point_count=400, shuffle=False),  # raster order: deep chains
+    dict(n_per=9000, seed=6, noise=0.30, k=4, th_point_count=3, cos_th=0.5),
+])
+def test_speculative_grow_stress(gpu_ctx, oracle, cfg):
+    xyz, nrm = _noisy_walls(cfg["n_per"], cfg["seed"], cfg["noise"], cfg.get("shuffle", True))
+    k = cfg["k"]
+    neigh = oracle.knn_normals(xyz, k=k, want_normals=False)[0]
+    kw = dict(th_point_count=cfg["th_point_count"])
+    if "cos_th" in cfg:
+        kw["cos_th"] = cfg["cos_th"]
+    _check_grow_mode(gpu_ctx, oracle, xyz, nrm, neigh, 2, **kw)
+
+
+def test_speculative_grow_urban_400k(gpu_ctx, oracle):
+    """Many independent faces: the multi-plane path proper (pending planes,
+    dead-plane reclaim, several rounds)."""
+    xyz = synth.urban(400_000, seed=9)
+    neigh, normals = gpu_ctx.knn_normals(xyz, api.default_params(k=16))
+    _check_grow_mode(gpu_ctx, oracle, xyz, normals, neigh, 2)
+    assert gpu_ctx.timings()["rg_rounds"] >= 1
+
+
+def test_bench_workload_facade_1m_full_parity(gpu_ctx, oracle):
+    """The bench.py N=1 workload (BASELINE.json configs[1]) end to end against
+    the oracle: every neighbour index, normal, label and plane list."""
+    xyz = synth.facade(n_side=1000, seed=2)
+    p = api.default_params(k=16)
+    neigh, normals, plane_idx, planes = gpu_ctx.segment(xyz, p)
+    oneigh, onormals = oracle.knn_normals(xyz, k=16)
+    assert np.array_equal(neigh, oneigh)
+    assert np.array_equal(normals, onormals)
+    opi, opl = oracle.region_grow(xyz, onormals, oneigh)
+    assert np.array_equal(plane_idx, opi)
+    assert [len(q.pointIdx) for q in planes] == np.diff(opl["offset"]).tolist()
+    assert np.array_equal(np.concatenate([q.pointIdx for q in planes]), opl["point_idx"])
+    # size-independent properties at full size
+    d = xyz[neigh].astype(np.int64) - xyz[:, None, :].astype(np.int64)
+    d2 = (d * d).sum(-1)
+    assert (np.diff(d2, axis=1) >= 0).all() and (neigh[:, 0] == np.arange(len(xyz))).all()
+    assert np.abs(np.linalg.norm(normals, axis=1) - 1).max() < 1e-12 and (normals[:, 2] >= 0).all()
+    labelled = plane_idx[plane_idx > 0]
+    assert labelled.max() <= len(planes) + 1 and (plane_idx != 0).all()
