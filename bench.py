@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="facade_1m", choices=["facade_1m", "urban_10m", "plane_cube_100k",
-                                                                "uniform_1m", "urban_2m"])
+                                                                "uniform_1m", "urban_2m", "urban_50m"])
     ap.add_argument("--k", type=int, default=0, help="neighbour-list length (0 = workload default)")
     ap.add_argument("--rg-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -47,6 +47,8 @@ def make_cloud(name: str, rank: int):
         return synth.facade(n_side=1000, seed=2 + 100 * rank), 16
     if name == "urban_10m":
         return synth.urban(10_000_000, seed=3 + 100 * rank), 32
+    if name == "urban_50m":
+        return synth.urban(50_000_000, seed=4 + 100 * rank), 16
     if name == "urban_2m":
         return synth.urban(2_000_000, seed=3 + 100 * rank), 16
     if name == "plane_cube_100k":

@@ -168,6 +168,13 @@ __global__ void orphan_pass_kernel(const uint32_t* __restrict__ hmask, const int
   uint32_t m = hmask[i];
   if (m == 0 || ps[i] || prev[i] < (int32_t)i)
     return;  // attempt i does not happen (already kept by a lower attempt) or is a plane handled apart
+  // Gauss-Seidel flavour: claims already made in THIS pass by lower attempts
+  // (blocks run roughly in index order) are used as well.  next[i] only
+  // decreases towards its final value, so at the fixed point (next == prev) the
+  // test equals the Jacobi one: the termination certificate is unchanged, the
+  // information just travels up the index order faster.
+  if (__hip_atomic_load(next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int32_t)i)
+    return;
   const int32_t* row = neigh + i * K;
   while (m) {
     const int t = __ffs(m) - 1;
