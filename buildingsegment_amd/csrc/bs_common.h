@@ -111,7 +111,7 @@ struct bs_ctx {
   // pipeline scratch (bs_segment_dev with NULL outputs)
   bs::DevBuf seg_neigh, seg_normals;
   // region-grow state
-  bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec;
+  bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec, rg_radj;
   int64_t rg_n = 0;
   bool rg_valid = false;
   // cell-sorted order of the last grid build (vals_out): spatially coherent iteration for gathers

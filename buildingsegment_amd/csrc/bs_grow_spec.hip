@@ -157,38 +157,77 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
   hmask[i] = m;
 }
 
-// ---- orphan-maker fixed point ------------------------------------------------
-__global__ void orphan_pass_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                   int64_t n, int32_t F, const uint8_t* __restrict__ ps,
-                                   const int32_t* __restrict__ prev, int32_t* __restrict__ next)
+// ---- orphan-maker fixed point (dynamic, pull based) ----------------------------
+// owner[c] = min( base[c], min{ j in R(c) : occ[j] } ),   occ[j] = maker(j) && owner[j] >= j
+// R(c) = reverse lists of the static masks (who may claim c), built once.  The
+// state (owner, occ) persists over the whole call; inserting or dropping a plane
+// only marks the touched points dirty and pull_pass_kernel re-evaluates dirty
+// points until nothing flips.  Dependencies only run from lower to higher
+// indices, so the iteration settles bottom-up to the unique fixed point; work is
+// proportional to what actually changes, not to n.
+__global__ void rev_count_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
+                                 int64_t n, int32_t* __restrict__ rcnt)
 {
-  const int64_t i = F + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n)
     return;
   uint32_t m = hmask[i];
-  if (m == 0 || ps[i] || prev[i] < (int32_t)i)
-    return;  // attempt i does not happen (already kept by a lower attempt) or is a plane handled apart
-  // Gauss-Seidel flavour: claims already made in THIS pass by lower attempts
-  // (blocks run roughly in index order) are used as well.  next[i] only
-  // decreases towards its final value, so at the fixed point (next == prev) the
-  // test equals the Jacobi one: the termination certificate is unchanged, the
-  // information just travels up the index order faster.
-  if (__hip_atomic_load(next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int32_t)i)
-    return;
   const int32_t* row = neigh + i * K;
   while (m) {
     const int t = __ffs(m) - 1;
     m &= m - 1;
-    atomicMin(&next[row[t + 1]], (int32_t)i);
+    atomicAdd(&rcnt[row[t + 1]], 1);
   }
 }
 
-__global__ void diff_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int64_t n, int* changed)
+__global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
+                                int64_t n, const int32_t* __restrict__ roff, int32_t* __restrict__ rpos,
+                                int32_t* __restrict__ radj)
 {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const bool d = i < n && a[i] != b[i];
-  if (__ballot(d) && (threadIdx.x & 63) == 0)
-    *changed = 1;
+  if (i >= n)
+    return;
+  uint32_t m = hmask[i];
+  const int32_t* row = neigh + i * K;
+  while (m) {
+    const int t = __ffs(m) - 1;
+    m &= m - 1;
+    const int32_t c = row[t + 1];
+    radj[roff[c] + atomicAdd(&rpos[c], 1)] = (int32_t)i;
+  }
+}
+
+__global__ void pull_pass_kernel(int64_t n, int K, const uint32_t* __restrict__ hmask,
+                                 const int32_t* __restrict__ neigh, const uint8_t* __restrict__ ps,
+                                 const int32_t* __restrict__ base, const int32_t* __restrict__ roff,
+                                 const int32_t* __restrict__ radj, int32_t* __restrict__ omega, uint8_t* occ,
+                                 uint8_t* dirty_cur, uint8_t* dirty_next, int* any)
+{
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= n || !dirty_cur[c])
+    return;
+  dirty_cur[c] = 0;
+  int32_t v = base[c];
+  const int32_t e1 = roff[c + 1];
+  for (int32_t e = roff[c]; e < e1; e++) {
+    const int32_t j = radj[e];
+    if (j < v && __hip_atomic_load(occ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      v = j;
+  }
+  omega[c] = v;
+  const uint32_t m0 = hmask[c];
+  const uint8_t want = (m0 != 0 && !ps[c] && v >= (int32_t)c) ? 1 : 0;
+  if (want != occ[c]) {
+    __hip_atomic_store(occ + c, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t* row = neigh + c * K;
+    uint32_t m = m0;
+    while (m) {
+      const int t = __ffs(m) - 1;
+      m &= m - 1;
+      dirty_next[row[t + 1]] = 1;
+    }
+    *any = 1;
+  }
 }
 
 // ---- plane-attempt candidates -------------------------------------------------
@@ -552,7 +591,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
 
 // every accepted point must still carry this plane's claim
 __global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
-                                                       int4* rec, int quads, uint8_t* ps)
+                                                       int4* rec, int quads)
 {
   const int w = blockIdx.x;
   if (w >= ncand || out[w].status != ST_DONE)
@@ -561,26 +600,43 @@ __global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand,
   bool bad = false;
   for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64)
     bad = bad || *rec_tag(rec, quads, pool[o.list_off + t]) != o.seed;
-  if (__ballot(bad)) {
-    if (threadIdx.x == 0)
+  const unsigned long long b = __ballot(bad);
+  if (threadIdx.x == 0) {
+    if (b)
       out[w].status = ST_STOLEN;
-  } else if (threadIdx.x == 0) {
-    ps[o.seed] = 1;
+    else
+      out[w].pad = 1;  // insert command for plane_apply_kernel
   }
 }
 
-// kept points of finished, committed planes enter the base owner array
-__global__ __launch_bounds__(64) void insert_kernel(const PlaneOut* __restrict__ out, int ncand,
-                                                    const int32_t* __restrict__ pool, int32_t* base)
+// A finished plane enters the owner structure: its seed stops being an orphan
+// maker and its kept points get the plane as base owner.  drop undoes it.
+// (PlaneOut.pad carries the host's per-plane command: 1 = insert, 2 = drop.)
+__global__ __launch_bounds__(64) void plane_apply_kernel(const PlaneOut* __restrict__ arr, int cnt,
+                                                         const int32_t* __restrict__ pool, int32_t* base,
+                                                         uint8_t* ps, uint8_t* dirty)
 {
   const int w = blockIdx.x;
-  if (w >= ncand)
+  if (w >= cnt)
     return;
-  const PlaneOut o = out[w];
-  if (o.status != ST_DONE || !o.keep)
+  const PlaneOut o = arr[w];
+  if (o.status != ST_DONE || o.pad == 0)
     return;
-  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64)
-    atomicMin(&base[pool[o.list_off + t]], o.seed);
+  const bool ins = o.pad == 1;
+  if (threadIdx.x == 0) {
+    ps[o.seed] = ins ? 1 : 0;
+    dirty[o.seed] = 1;
+  }
+  if (!o.keep)
+    return;
+  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64) {
+    const int32_t p = pool[o.list_off + t];
+    if (ins)
+      atomicMin(&base[p], o.seed);
+    else
+      atomicCAS(&base[p], o.seed, INF);
+    dirty[p] = 1;
+  }
 }
 
 __global__ __launch_bounds__(64) void validate2_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
@@ -606,28 +662,20 @@ __global__ __launch_bounds__(64) void validate2_kernel(PlaneOut* out, int ncand,
     out[w].consistent = b ? 0 : 1;
 }
 
-__global__ void mark_ps_kernel(const PlaneOut* __restrict__ arr, int cnt, uint8_t* ps)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cnt && arr[i].status == ST_DONE)
-    ps[arr[i].seed] = 1;
-}
+struct CopyDesc {
+  const int32_t* src;
+  int32_t* dst;
+  int64_t cnt;
+};
 
-__global__ void finalize_owner_kernel(const int32_t* __restrict__ omega, int32_t first_bad, int64_t n,
-                                      int32_t* __restrict__ owner_final)
+__global__ void copy_lists_kernel(const CopyDesc* __restrict__ d, int nd)
 {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n)
+  const int w = blockIdx.x;
+  if (w >= nd)
     return;
-  const int32_t o = omega[i];
-  owner_final[i] = o < first_bad ? o : INF;
-}
-
-__global__ void copy_list_kernel(const int32_t* __restrict__ pool, int64_t src, int64_t cnt, int32_t* dst)
-{
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < cnt)
-    dst[i] = pool[src + i];
+  const CopyDesc c = d[w];
+  for (int64_t i = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; i < c.cnt; i += (int64_t)gridDim.y * blockDim.x)
+    c.dst[i] = c.src[i];
 }
 
 __global__ void label_kernel(const int32_t* __restrict__ owner, int64_t n, const int32_t* __restrict__ seeds,
@@ -663,70 +711,49 @@ inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
 
 }  // namespace
 
-// Jacobi iteration of the orphan-maker system to its fixed point.
-// base: owners that are given (finals + inserted planes); result in *result.
-static int orphan_fixpoint(bs_ctx* ctx, const uint32_t* hmask, const int32_t* neigh, int K, int64_t n, int32_t F,
-                           const uint8_t* ps, const int32_t* base, int32_t* bufA, int32_t* bufB, int* d_changed,
-                           int32_t** result, int64_t* passes)
-{
-  hipStream_t st = ctx->stream;
-  int32_t* prev = bufA;
-  int32_t* next = bufB;
-  BS_HIP(ctx, hipMemcpyAsync(prev, base, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
-  const int64_t m = n - F;
-  for (int it = 0; it < 100000; it++) {
-    BS_HIP(ctx, hipMemcpyAsync(next, base, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
-    if (m > 0)
-      orphan_pass_kernel<<<nblk(m, 256), 256, 0, st>>>(hmask, neigh, K, n, F, ps, prev, next);
-    BS_HIP(ctx, hipMemsetAsync(d_changed, 0, sizeof(int), st));
-    diff_kernel<<<nblk(n, 256), 256, 0, st>>>(prev, next, n, d_changed);
-    int ch = 0;
-    BS_HIP(ctx, hipMemcpyAsync(&ch, d_changed, sizeof ch, hipMemcpyDeviceToHost, st));
-    BS_HIP(ctx, hipStreamSynchronize(st));
-    (*passes)++;
-    std::swap(prev, next);
-    if (!ch) {
-      *result = prev;
-      return BS_OK;
-    }
-  }
-  return fail(ctx, BS_ERR_INTERNAL, "orphan fixed point did not converge");
-}
-
 int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
                             int64_t n, const bs_params& p, int32_t* d_plane_idx)
 {
   hipStream_t st = ctx->stream;
   ctx->rg_valid = false;
   const int K = p.k;
+  if (n * (int64_t)(K - 1) >= (int64_t)INT32_MAX)
+    return fail(ctx, BS_ERR_INVALID, "n * (k - 1) must fit in int32 (reverse edge list)");
   const int64_t list_cap = 2 * n + 64;
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;
   // round pool: lists + stacks + logs of every concurrent attempt
-  const unsigned long long pool_cap =
-      (unsigned long long)std::max<int64_t>(std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * 32) * 2 * MAX_WAVES);
+  const unsigned long long pool_cap = (unsigned long long)std::max<int64_t>(
+      std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * 32) * 2 * MAX_WAVES);
   BS_HIP(ctx, ctx->rg_list.reserve(sizeof(int32_t) * list_cap));
   BS_HIP(ctx, ctx->rg_planes.reserve(sizeof(PlaneRec) * planes_cap));
   BS_HIP(ctx, ctx->rg_stats.reserve(sizeof(GrowStats)));
-  // aux layout (int32 units): misc[1024] | hmask | owner_final | bufA | bufB | base | tag | cand | seeds |
-  //                            flags(u8) | ps(u8) | PlaneOut[MAX_WAVES]
-  const size_t aux_bytes = sizeof(int32_t) * (size_t)(8 * n + planes_cap + 1024 + 64) + (size_t)2 * n + 4096 +
-                           sizeof(PlaneOut) * (MAX_WAVES + MAX_PENDING);
+  // aux layout (int32 units): misc[1024] | hmask | omega | base | dead | cand | roff(n+2) | rpos | seeds |
+  //                            (u8) flags | ps | occ | dirty0 | dirty1 | PlaneOut[MAX_WAVES + MAX_PENDING] | CopyDesc[]
+  const size_t n_i32 = (size_t)(7 * n + planes_cap + 1024 + 128);
+  const size_t aux_bytes = sizeof(int32_t) * n_i32 + (size_t)5 * n + 8192 +
+                           sizeof(PlaneOut) * (MAX_WAVES + MAX_PENDING) + sizeof(CopyDesc) * (MAX_WAVES + MAX_PENDING);
   BS_HIP(ctx, ctx->rg_aux.reserve(aux_bytes));
   BS_HIP(ctx, ctx->rg_stack.reserve(sizeof(int32_t) * pool_cap));
+  BS_HIP(ctx, ctx->rg_radj.reserve(sizeof(int32_t) * (size_t)(n * (K - 1) + 16)));
   int32_t* aux = ctx->rg_aux.as<int32_t>();
-  int32_t* d_misc = aux;  // [0]=changed [1]=ncand [2]=min_idx ; [16..17] pool top (u64)
+  int32_t* d_misc = aux;  // [0]=any [1]=ncand [2]=min_idx ; [16..17] pool top (u64)
   uint32_t* hmask = (uint32_t*)(aux + 1024);
-  int32_t* owner_final = aux + 1024 + n;
-  int32_t* bufA = aux + 1024 + 2 * n;
-  int32_t* bufB = aux + 1024 + 3 * n;
-  int32_t* base = aux + 1024 + 4 * n;
-  int32_t* dead = aux + 1024 + 6 * n;    // directly after tag
-  int32_t* d_cand = aux + 1024 + 7 * n;  // select output (n entries)
-  int32_t* d_seeds = aux + 1024 + 8 * n;  // committed seeds (planes_cap)
-  uint8_t* flags = (uint8_t*)(aux + 1024 + 8 * n + planes_cap + 64);
+  int32_t* omega = aux + 1024 + n;
+  int32_t* base = aux + 1024 + 2 * n;
+  int32_t* dead = aux + 1024 + 3 * n;
+  int32_t* d_cand = aux + 1024 + 4 * n;  // select output (n entries)
+  int32_t* roff = aux + 1024 + 5 * n;    // n + 1 (+ pad)
+  int32_t* rpos = aux + 1024 + 6 * n + 64;
+  int32_t* d_seeds = aux + 1024 + 7 * n + 64;  // committed seeds (planes_cap)
+  uint8_t* flags = (uint8_t*)(aux + n_i32);
   uint8_t* ps = flags + n;
-  PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(ps + n) + 255) & ~(uintptr_t)255);
+  uint8_t* occ = ps + n;
+  uint8_t* dirty0 = occ + n;
+  uint8_t* dirty1 = dirty0 + n;
+  PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(dirty1 + n) + 255) & ~(uintptr_t)255);
   PlaneOut* d_pend = d_out + MAX_WAVES;
+  CopyDesc* d_copy = (CopyDesc*)(d_pend + MAX_PENDING);
+  int32_t* radj = ctx->rg_radj.as<int32_t>();
   unsigned long long* d_pool_top = (unsigned long long*)(d_misc + 16);
   Pool pool = {ctx->rg_stack.as<int32_t>(), d_pool_top, pool_cap};
 
@@ -740,7 +767,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   a.cos_th = p.cos_th;
   a.th_count = p.th_point_count;
   a.F = 0;
-  a.vec = ((K & 3) == 0 && ((uintptr_t)d_neigh & 15) == 0) ? 1 : 0;
+  a.vec = 0;
 
   const int KC = K <= 16 ? 16 : 32;
   const int quads = 4 + KC / 4;
@@ -752,8 +779,52 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec);
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
   static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, order, hmask);
-  fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, INF);
+  // reverse lists of the static masks
+  BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
+  rev_count_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, rpos);
+  {
+    size_t tb = 0;
+    BS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rpos, roff, (int)n, st));
+    BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
+    BS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tb, rpos, roff, (int)n, st));
+    // roff[n] = roff[n-1] + rcnt[n-1]
+    int32_t last_off = 0, last_cnt = 0;
+    BS_HIP(ctx, hipMemcpyAsync(&last_off, roff + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    BS_HIP(ctx, hipMemcpyAsync(&last_cnt, rpos + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    BS_HIP(ctx, hipStreamSynchronize(st));
+    const int32_t total = last_off + last_cnt;
+    BS_HIP(ctx, hipMemcpyAsync(roff + n, &total, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  }
+  BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
+  rev_fill_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, roff, rpos, radj);
+  // initial state: no plane, every point dirty, nobody occurs yet (the first pass sets occ)
+  fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
+  fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, n, INF);
   BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
+  BS_HIP(ctx, hipMemsetAsync(occ, 0, n, st));
+  BS_HIP(ctx, hipMemsetAsync(dirty0, 1, n, st));
+  BS_HIP(ctx, hipMemsetAsync(dirty1, 0, n, st));
+  uint8_t* dcur = dirty0;
+  uint8_t* dnext = dirty1;
+  int64_t passes = 0;
+  auto propagate = [&]() -> int {
+    for (int it = 0; it < 1000000; it++) {
+      BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
+      pull_pass_kernel<<<nblk(n, 256), 256, 0, st>>>(n, K, hmask, d_neigh, ps, base, roff, radj, omega, occ, dcur,
+                                                     dnext, d_misc);
+      int any = 0;
+      BS_HIP(ctx, hipMemcpyAsync(&any, d_misc, sizeof any, hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipStreamSynchronize(st));
+      passes++;
+      std::swap(dcur, dnext);  // dcur now holds the newly dirtied points (the old dcur was cleared by the pass)
+      if (!any)
+        return BS_OK;
+    }
+    return fail(ctx, BS_ERR_INTERNAL, "orphan fixed point did not converge");
+  };
+  int rc = propagate();
+  if (rc != BS_OK)
+    return rc;
 
   // persistent store for planes that finished consistently but cannot be
   // finalised yet (an earlier attempt is still open): kept across rounds and
@@ -767,7 +838,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   std::vector<PlaneRec> recs;
   std::vector<int32_t> seeds;
   std::vector<PlaneOut> h_out(MAX_WAVES), h_pend;
-  int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0, passes = 0;
+  std::vector<CopyDesc> copies;
+  int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0;
   int32_t F = 0;
   size_t sel_tmp = 0;
   {
@@ -781,8 +853,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       return BS_OK;  // rolled back: no trace
     if (list_used + o.list_n > list_cap || (int64_t)recs.size() >= planes_cap)
       return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): list pool overflow");
-    copy_list_kernel<<<nblk(o.list_n, 256), 256, 0, st>>>(src_pool, o.list_off, o.list_n,
-                                                          ctx->rg_list.as<int32_t>() + list_used);
+    copies.push_back({src_pool + o.list_off, ctx->rg_list.as<int32_t>() + list_used, o.list_n});
     PlaneRec r;
     for (int c = 0; c < 3; c++) {
       r.normal[c] = o.normal[c];
@@ -799,35 +870,25 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     largest = std::max<int64_t>(largest, o.list_n);
     return BS_OK;
   };
+  auto flush_copies = [&]() -> int {
+    for (size_t off = 0; off < copies.size(); off += MAX_WAVES + MAX_PENDING) {
+      const int nd = (int)std::min<size_t>(copies.size() - off, MAX_WAVES + MAX_PENDING);
+      BS_HIP(ctx, hipMemcpyAsync(d_copy, copies.data() + off, sizeof(CopyDesc) * nd, hipMemcpyHostToDevice, st));
+      copy_lists_kernel<<<dim3(nd, 8), 256, 0, st>>>(d_copy, nd);
+      BS_HIP(ctx, hipStreamSynchronize(st));  // descriptors are reused
+    }
+    copies.clear();
+    return BS_OK;
+  };
   int max_waves = 2048;
-  int32_t* reuse_omega = nullptr;
   if (const char* e = getenv("BS_MAX_WAVES"))
     max_waves = std::max(1, std::min(MAX_WAVES, atoi(e)));
   for (;;) {
     rounds++;
     a.F = F;
     const int npend = (int)pending.size();
-    // owner base = finals + pending planes (their seeds are not orphan makers)
-    BS_HIP(ctx, hipMemcpyAsync(base, owner_final, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
-    BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
-    if (npend) {
-      BS_HIP(ctx, hipMemcpyAsync(d_pend, pending.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
-      mark_ps_kernel<<<nblk(npend, 256), 256, 0, st>>>(d_pend, npend, ps);
-      insert_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, base);
-    }
-    // tentative owners with every other open attempt treated as an orphan maker.
-    // When the previous round dropped no plane, its closing fixed point was
-    // computed over exactly this base and plane-seed set: reuse it.
-    int32_t* omega = nullptr;
-    int rc = BS_OK;
-    if (reuse_omega) {
-      omega = reuse_omega;
-    } else {
-      rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, base, bufA, bufB, d_misc, &omega, &passes);
-      if (rc != BS_OK)
-        return rc;
-    }
-    // lowest new plane-attempt candidates
+    // lowest new plane-attempt candidates under the current owners (pending
+    // planes are in the structure, their seeds are not candidates)
     cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, flags, nullptr);
     {
       hipcub::CountingInputIterator<int32_t> it(0);
@@ -837,15 +898,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     int32_t ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
-    if (ncand_all == 0 && npend == 0) {
-      // no plane attempt left: the fixed point is the final owner array
-      BS_HIP(ctx, hipMemcpyAsync(owner_final, omega, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
-      break;
-    }
+    if (ncand_all == 0 && npend == 0)
+      break;  // no plane attempt left: omega is the final owner array
     const int ncand = std::min<int>(ncand_all, max_waves);
-    int32_t* omega2 = omega;
+    if (npend)
+      BS_HIP(ctx, hipMemcpyAsync(d_pend, pending.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
     if (ncand > 0) {
-      // grow them concurrently
+      // grow them concurrently against the current owners
       refresh_records_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, rec, quads, n);
       BS_HIP(ctx, hipMemsetAsync(dead, 0, sizeof(int32_t) * n, st));
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
@@ -853,19 +912,19 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
       else
         grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
-      validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, rec, quads, ps);
-      // insert the finished planes and recompute the fixed point
-      insert_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base);
-      rc = orphan_fixpoint(ctx, hmask, d_neigh, K, n, F, ps, base, bufA, bufB, d_misc, &omega2, &passes);
+      validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, rec, quads);
+      // insert the finished planes and let the owners settle
+      plane_apply_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
+      rc = propagate();
       if (rc != BS_OK)
         return rc;
-      validate2_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, omega2, d_neigh, K);
+      validate2_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, omega, d_neigh, K);
     }
     if (npend)
-      validate2_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, omega2, d_neigh, K);
+      validate2_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, omega, d_neigh, K);
     int32_t inf = INF;
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 2, &inf, sizeof inf, hipMemcpyHostToDevice, st));
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega2, nullptr, d_misc + 2);
+    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, d_misc + 2);
     int32_t new_min = INF;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
     if (ncand)
@@ -913,22 +972,26 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
               npend, pcons, first_bad, new_min, (long)maxsteps, (long)sumsteps, (long)maxlist, (long)passes);
     }
     // merge pending and new planes in seed order: below first_bad -> final,
-    // consistent ones above it stay pending, the rest is dropped
+    // consistent ones above it stay pending, the rest is dropped from the structure
     std::vector<PlaneOut> next_pending;
     int finals = 0, dropped = 0;
     {
       int ip = 0, iw = 0;
       while (ip < npend || iw < ncand) {
         const bool take_p = (iw >= ncand) || (ip < npend && h_pend[ip].seed < h_out[iw].seed);
-        const PlaneOut& o = take_p ? h_pend[ip] : h_out[iw];
+        PlaneOut& o = take_p ? h_pend[ip] : h_out[iw];
         const int32_t* src = take_p ? pstore : pool.base;
         if (take_p)
           ip++;
         else
           iw++;
-        if (o.status != ST_DONE || !o.consistent) {
-          dropped += take_p ? 1 : 0;  // an invalidated pending plane re-enters as a candidate
-          continue;
+        o.pad = 0;  // command for plane_apply_kernel: 2 = drop
+        if (o.status != ST_DONE)
+          continue;  // never entered the structure
+        if (!o.consistent) {
+          o.pad = 2;
+          dropped++;
+          continue;  // re-enters as a candidate (or orphan maker) next round
         }
         if (o.seed < first_bad) {
           finals++;
@@ -940,52 +1003,47 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         } else if ((int)next_pending.size() < MAX_PENDING && pstore_top + o.list_n + o.log_n + 8 <= pstore_cap) {
           PlaneOut q = o;
           q.list_off = pstore_top;
-          copy_list_kernel<<<nblk(o.list_n, 256), 256, 0, st>>>(pool.base, o.list_off, o.list_n, pstore + q.list_off);
+          copies.push_back({pool.base + o.list_off, pstore + q.list_off, o.list_n});
           pstore_top += (o.list_n + 3) & ~(int64_t)3;
           q.log_off = pstore_top;
           if (o.log_n)
-            copy_list_kernel<<<nblk(o.log_n, 256), 256, 0, st>>>(pool.base, o.log_off, o.log_n, pstore + q.log_off);
+            copies.push_back({pool.base + o.log_off, pstore + q.log_off, o.log_n});
           pstore_top += (o.log_n + 3) & ~(int64_t)3;
           next_pending.push_back(q);
+        } else {
+          o.pad = 2;  // no room to keep it: drop, it will be grown again
+          dropped++;
         }
       }
+    }
+    rc = flush_copies();
+    if (rc != BS_OK)
+      return rc;
+    if (dropped) {
+      if (ncand) {
+        BS_HIP(ctx, hipMemcpyAsync(d_out, h_out.data(), sizeof(PlaneOut) * ncand, hipMemcpyHostToDevice, st));
+        plane_apply_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
+      }
+      if (npend) {
+        BS_HIP(ctx, hipMemcpyAsync(d_pend, h_pend.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
+        plane_apply_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, base, ps, dcur);
+      }
+      rc = propagate();
+      if (rc != BS_OK)
+        return rc;
     }
     pending.swap(next_pending);
     if (pending.empty())
       pstore_top = 0;
-    {
-      // every inserted plane stays inserted (as final or pending) iff none was invalid or lost
-      bool all_kept = dropped == 0;
-      for (int w = 0; w < ncand && all_kept; w++)
-        if (h_out[w].status == ST_DONE && !h_out[w].consistent)
-          all_kept = false;
-      int64_t kept = 0, done = 0;
-      for (int w = 0; w < ncand; w++)
-        done += h_out[w].status == ST_DONE && h_out[w].seed >= first_bad;
-      for (const PlaneOut& q : pending)
-        kept += 1;
-      // (a consistent new plane above first_bad that did not fit into the pending store is lost)
-      int64_t old_above = 0;
-      for (int w = 0; w < npend; w++)
-        old_above += h_pend[w].seed >= first_bad;
-      if (kept != done + old_above)
-        all_kept = false;
-      reuse_omega = all_kept ? omega2 : nullptr;
-    }
-    if (first_bad == INF) {
-      // no open plane attempt is left (an ungrown candidate would have shown up
-      // in new_min; every pending plane was consistent and has been committed):
-      // every remaining attempt is an orphan maker and omega2 is their fixed point
-      BS_HIP(ctx, hipMemcpyAsync(owner_final, omega2, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st));
-      break;
-    }
-    finalize_owner_kernel<<<nblk(n, 256), 256, 0, st>>>(omega2, first_bad, n, owner_final);
+    if (first_bad == INF)
+      break;  // every plane attempt is final; omega holds the remaining orphan makers' fixed point
     if (finals == 0 && dropped == 0 && !nomem_lowest && first_bad <= F)
       return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): no progress");
     F = first_bad;
     if (rounds > 4 * n + 16)
       return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): round limit");
   }
+  int32_t* owner_final = omega;
   // labels and plane records
   const int np = (int)recs.size();
   if (np > 0) {
