@@ -163,6 +163,15 @@ def main():
         else:
             dom, dbytes, dms = "knn_normals", knn_bytes, stage["knn_ms"]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        # HBM bytes per launch of the dominant stage from the committed rocprofv3 PMC passes
+        # (tools/pmc_traffic.py; counters cannot be read live from inside the bench)
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("workload") == args.workload:
+                traffic = pt["region_grow_stage_bytes_per_call" if dom == "region_grow" else "knn_fast_kernel_bytes_per_call"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "Mpoints/s segmented (kNN+normal+label)",
             "value": value,
@@ -183,7 +192,7 @@ def main():
             "stages_ms": stage,
             "end_to_end_alg_GBps": n * (88 + 8 * k) / (elapsed / steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": dbytes, "avg_ms": dms},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -134,23 +134,31 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int64_t used, int6
 
 // ---- (a) static depth-0 mask ------------------------------------------------
 // order (nullable): a spatially coherent permutation (the grid's cell-sorted
-// order), so that the neighbour gathers of adjacent threads share cache lines
-__global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order, uint32_t* __restrict__ hmask)
+// order), so that the neighbour gathers of adjacent threads share cache lines.
+// Neighbour geometry comes from the one-line-per-point records.
+__global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order, const int4* __restrict__ rec,
+                                   int quads, uint32_t* __restrict__ hmask)
 {
   const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s >= a.n)
     return;
   const int64_t i = order ? order[s] : s;
-  const double cnx = a.normals[3 * i], cny = a.normals[3 * i + 1], cnz = a.normals[3 * i + 2];
-  const int ccx = a.xyz[3 * i], ccy = a.xyz[3 * i + 1], ccz = a.xyz[3 * i + 2];
+  const int4* ri = rec + i * quads;
+  const int4 s0 = ri[0], s1 = ri[1], s2 = ri[2];
+  const double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z),
+               cnz = __hiloint2double(s2.y, s2.x);
+  const int ccx = s0.x, ccy = s0.y, ccz = s0.z;
+  const int32_t* row = reinterpret_cast<const int32_t*>(ri + 4);
   uint32_t m = 0;
   for (int t = 1; t < a.K; t++) {
-    const int64_t c = a.neigh[i * a.K + t];
-    const int dx = (int)((uint32_t)a.xyz[3 * c] - (uint32_t)ccx);
-    const int dy = (int)((uint32_t)a.xyz[3 * c + 1] - (uint32_t)ccy);
-    const int dz = (int)((uint32_t)a.xyz[3 * c + 2] - (uint32_t)ccz);
+    const int4* rc = rec + (int64_t)row[t] * quads;
+    const int4 q0 = rc[0], q1 = rc[1], q2 = rc[2];
+    const int dx = (int)((uint32_t)q0.x - (uint32_t)ccx);
+    const int dy = (int)((uint32_t)q0.y - (uint32_t)ccy);
+    const int dz = (int)((uint32_t)q0.z - (uint32_t)ccz);
     const double dist = __builtin_fabs((double)dx * cnx + (double)dy * cny + (double)dz * cnz);
-    const double dt = cnx * a.normals[3 * c] + cny * a.normals[3 * c + 1] + cnz * a.normals[3 * c + 2];
+    const double dt = cnx * __hiloint2double(q1.y, q1.x) + cny * __hiloint2double(q1.w, q1.z) +
+                      cnz * __hiloint2double(q2.y, q2.x);
     if (dist <= a.th && dt >= a.cos_th)
       m |= 1u << (t - 1);
   }
@@ -778,7 +786,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   else
     build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec);
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
-  static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, order, hmask);
+  static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, order, rec, quads, hmask);
   // reverse lists of the static masks
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
   rev_count_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, rpos);
