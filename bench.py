@@ -133,13 +133,15 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    stage = {"grid_ms": 0.0, "knn_ms": 0.0, "grow_ms": 0.0}
+    stage = {"grid_ms": 0.0, "knn_ms": 0.0, "grow_ms": 0.0, "grow_kernel_ms": 0.0}
+    launches = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         tm = ctx.timings()  # HIP-event stage times of this step (events on the launch stream)
         for kk in stage:
             stage[kk] += tm[kk]
+        launches += tm["grow_kernel_launches"]
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -153,24 +155,33 @@ def main():
 
     if rank == 0:
         value = world * n * args.steps / elapsed / 1e6
-        # dominant kernel by time; algorithmic bytes per point:
-        #   kNN+normals stage: read xyz 12 + write k*4 + write normal 24
-        #   region grow stage: read neigh row k*4 + xyz 12 + normal 24 + write label 4
-        grow_bytes = n * (4 * k + 40)
+        # Dominant kernel by time.  Algorithmic bytes per point:
+        #   kNN+normals: read xyz 12 + write k*4 + write normal 24 (+12: second read of xyz)
+        #   region grow: read neigh row k*4 + xyz 12 + normal 24 + write label 4
+        # One pass of region growing is spread over `launches/steps` launches of the
+        # plane-growth kernel (one per speculative round): bytes per launch = n(4k+40)/rounds,
+        # average launch duration from HIP events recorded around each launch on the stream.
+        lps = max(launches / steps, 1.0)
+        grow_bytes = n * (4 * k + 40) / lps
         knn_bytes = n * (4 * k + 36 + 12)
-        if stage["grow_ms"] >= stage["knn_ms"]:
-            dom, dbytes, dms = "region_grow", grow_bytes, stage["grow_ms"]
+        grow_avg = stage["grow_kernel_ms"] / lps
+        if stage["grow_kernel_ms"] >= stage["knn_ms"]:
+            dom = "grow_spec_kernel" if args.rg_mode != 1 else "grow_seq_kernel"
+            dbytes, dms = grow_bytes, grow_avg
         else:
-            dom, dbytes, dms = "knn_normals", knn_bytes, stage["knn_ms"]
+            dom, dbytes, dms = "knn_fast_kernel", knn_bytes, stage["knn_ms"]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-        # HBM bytes per launch of the dominant stage from the committed rocprofv3 PMC passes
-        # (tools/pmc_traffic.py; counters cannot be read live from inside the bench)
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+        # (tools/pmc_traffic.py; the counters cannot be read live from inside the bench)
         traffic = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("workload") == args.workload:
-                traffic = pt["region_grow_stage_bytes_per_call" if dom == "region_grow" else "knn_fast_kernel_bytes_per_call"]
-        except (OSError, ValueError, KeyError):
+            if pt.get("workload") == args.workload and args.rg_mode != 1:
+                if dom == "grow_spec_kernel":
+                    traffic = pt["grow_spec_kernel_bytes_per_call"] / lps
+                else:
+                    traffic = pt["knn_fast_kernel_bytes_per_call"]
+        except (OSError, ValueError, KeyError, TypeError):
             traffic = None
         out = {
             "metric": "Mpoints/s segmented (kNN+normal+label)",
@@ -193,7 +204,7 @@ def main():
             "end_to_end_alg_GBps": n * (88 + 8 * k) / (elapsed / steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": dbytes, "avg_ms": dms},
+                         "alg_bytes_per_launch": dbytes, "avg_ms": dms, "launches_per_step": lps},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(xyz, k)

@@ -72,6 +72,18 @@ __host__ __device__ inline uint32_t hash_cell(uint64_t k)
   return (uint32_t)(k >> 32) ^ (uint32_t)k;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  For
+// kernels that walk the cell-sorted order, map hardware block b to logical
+// block (b % 8) * (nb / 8) + b / 8 (grid padded to a multiple of 8) so that one
+// XCD sees one contiguous slice of space and spatial neighbours share its L2
+// (speed only; any mapping is correct).
+__device__ inline int64_t xcd_logical_block()
+{
+  const int64_t b = blockIdx.x, per = gridDim.x >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+inline int xcd_grid(int64_t nblocks) { return (int)((nblocks + 7) & ~(int64_t)7); }
+
 // ---- plane record produced by region growing ------------------------------
 struct PlaneRec {
   double normal[3];
@@ -101,7 +113,7 @@ struct bs_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   bs_timings tm{};
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
   // grid scratch
   bs::DevBuf keys_in, keys_out, vals_in, vals_out, cub_tmp, uniq_keys, uniq_cnt, misc;

@@ -258,7 +258,9 @@ int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_no
   a.planes_cap = (int32_t)std::min<int64_t>(planes_cap, INT32_MAX);
   a.stats = ctx->rg_stats.as<GrowStats>();
   a.step_cap = 512 * n + 4096;
+  (void)hipEventRecord(ctx->ev[6], st);
   grow_seq_kernel<<<1, 64, 0, st>>>(a);
+  (void)hipEventRecord(ctx->ev[7], st);
   BS_HIP(ctx, hipGetLastError());
   GrowStats hs;
   BS_HIP(ctx, hipMemcpyAsync(&hs, ctx->rg_stats.p, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -270,6 +272,12 @@ int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_no
   ctx->tm.largest_plane = hs.largest;
   ctx->tm.n_seed_attempts = hs.seed_attempts;
   ctx->tm.rg_rounds = 1;
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess)
+      ctx->tm.grow_kernel_ms = ms;
+    ctx->tm.grow_kernel_launches = 1;
+  }
   return BS_OK;
 }
 

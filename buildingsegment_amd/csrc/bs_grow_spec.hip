@@ -139,7 +139,7 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int64_t used, int6
 __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order, const int4* __restrict__ rec,
                                    int quads, uint32_t* __restrict__ hmask)
 {
-  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
   if (s >= a.n)
     return;
   const int64_t i = order ? order[s] : s;
@@ -174,11 +174,12 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
 // indices, so the iteration settles bottom-up to the unique fixed point; work is
 // proportional to what actually changes, not to n.
 __global__ void rev_count_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                 int64_t n, int32_t* __restrict__ rcnt)
+                                 int64_t n, const int32_t* __restrict__ order, int32_t* __restrict__ rcnt)
 {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n)
+  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= n)
     return;
+  const int64_t i = order ? order[s] : s;
   uint32_t m = hmask[i];
   const int32_t* row = neigh + i * K;
   while (m) {
@@ -189,12 +190,13 @@ __global__ void rev_count_kernel(const uint32_t* __restrict__ hmask, const int32
 }
 
 __global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                int64_t n, const int32_t* __restrict__ roff, int32_t* __restrict__ rpos,
-                                int32_t* __restrict__ radj)
+                                int64_t n, const int32_t* __restrict__ order, const int32_t* __restrict__ roff,
+                                int32_t* __restrict__ rpos, int32_t* __restrict__ radj)
 {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n)
+  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= n)
     return;
+  const int64_t i = order ? order[s] : s;
   uint32_t m = hmask[i];
   const int32_t* row = neigh + i * K;
   while (m) {
@@ -786,10 +788,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   else
     build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec);
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
-  static_mask_kernel<<<nblk(n, 256), 256, 0, st>>>(a, order, rec, quads, hmask);
+  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, order, rec, quads, hmask);
   // reverse lists of the static masks
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
-  rev_count_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, rpos);
+  rev_count_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, d_neigh, K, n, order, rpos);
   {
     size_t tb = 0;
     BS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rpos, roff, (int)n, st));
@@ -804,7 +806,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, hipMemcpyAsync(roff + n, &total, sizeof(int32_t), hipMemcpyHostToDevice, st));
   }
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
-  rev_fill_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, roff, rpos, radj);
+  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, d_neigh, K, n, order, roff, rpos, radj);
   // initial state: no plane, every point dirty, nobody occurs yet (the first pass sets occ)
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, n, INF);
@@ -847,7 +849,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   std::vector<int32_t> seeds;
   std::vector<PlaneOut> h_out(MAX_WAVES), h_pend;
   std::vector<CopyDesc> copies;
-  int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0;
+  int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0, grow_launches = 0;
+  double grow_ms = 0.0;
+  bool timed_round = false;
   int32_t F = 0;
   size_t sel_tmp = 0;
   {
@@ -916,10 +920,14 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       refresh_records_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, rec, quads, n);
       BS_HIP(ctx, hipMemsetAsync(dead, 0, sizeof(int32_t) * n, st));
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
+      (void)hipEventRecord(ctx->ev[6], st);
       if (KC == 16)
         grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
       else
         grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
+      (void)hipEventRecord(ctx->ev[7], st);
+      grow_launches++;
+      timed_round = true;
       validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, rec, quads);
       // insert the finished planes and let the owners settle
       plane_apply_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
@@ -941,6 +949,12 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     if (npend)
       BS_HIP(ctx, hipMemcpyAsync(h_pend.data(), d_pend, sizeof(PlaneOut) * npend, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
+    if (timed_round) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess)
+        grow_ms += ms;
+      timed_round = false;
+    }
     // first attempt (by seed index) whose result is not established
     int32_t first_bad = new_min;
     bool nomem_lowest = false;
@@ -1074,6 +1088,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   ctx->tm.largest_plane = largest;
   ctx->tm.n_seed_attempts = attempts;
   ctx->tm.rg_rounds = rounds;
+  ctx->tm.grow_kernel_ms = grow_ms;
+  ctx->tm.grow_kernel_launches = grow_launches;
   return BS_OK;
 }
 

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
                                                        int32_t* __restrict__ fb_count, uint64_t cert_r2,
                                                        unsigned long long* __restrict__ uncert)
 {
-  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
   if (s >= g.n)
     return;
   const int32_t loc = g.slocal[s];
@@ -360,14 +360,15 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
       cert_r2 = 1;
   }
   const int blocks = (int)((n + 255) / 256);
+  const int xblocks = xcd_grid(blocks);
   // fast kernel needs every candidate d^2 < 2^32
   const bool fast_ok = (int64_t)g.cell * (2 * BS_FAST_RINGS + 1) <= 37500;
   if (fast_ok) {
     if (p.k <= 16)
-      knn_fast_kernel<16><<<blocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+      knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
                                                   fb_list, fb_count, cert_r2, uncert);
     else
-      knn_fast_kernel<32><<<blocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+      knn_fast_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
                                                   fb_list, fb_count, cert_r2, uncert);
   } else {
     mark_all_kernel<<<blocks, 256, 0, st>>>(g, q_begin, q_end, fb_list, fb_count);

@@ -87,6 +87,8 @@ typedef struct bs_timings {
   int64_t n_seed_attempts;
   int64_t n_fallback_queries; /* queries that left the LDS-tile fast path */
   int64_t rg_rounds;      /* speculative rounds (rg_mode 2) */
+  double grow_kernel_ms;  /* sum of the plane-growth kernel launches alone (HIP events around each launch) */
+  int64_t grow_kernel_launches;
 } bs_timings;
 
 typedef struct bs_ctx bs_ctx;
