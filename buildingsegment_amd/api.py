@@ -169,6 +169,16 @@ class Context:
         self._check(self._L.bs_segment_dev(self._h, d_xyz, n, C.byref(params), d_neigh or None,
                                            d_normals or None, d_plane_idx))
 
+    def shift_to_origin_dev(self, d_xyz, n):
+        """buildingSeg ctor shift (TMC3.cpp:55-73) in place on the device; returns the minimum."""
+        mn = np.zeros(3, dtype=np.int32)
+        self._check(self._L.bs_shift_to_origin_dev(self._h, d_xyz, n, mn.ctypes.data))
+        return mn
+
+    def plane_colors_dev(self, plane_rgb, n, d_colors):
+        rgb = np.ascontiguousarray(plane_rgb, dtype=np.int32).reshape(-1, 3)
+        self._check(self._L.bs_plane_colors_dev(self._h, rgb.ctypes.data, len(rgb), n, d_colors))
+
     def planes_fetch(self):
         P = Planes()
         self._check(self._L.bs_planes_fetch(self._h, C.byref(P)))

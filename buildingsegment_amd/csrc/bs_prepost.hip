@@ -1,0 +1,118 @@
+// bs_prepost.hip -- the O(N) passes either side of the hot path, on the device
+// (SURVEY.md 8f-2,3): bounding-box shift of the buildingSeg constructor
+// (/root/reference/tmc3/TMC3.cpp:55-73) and the label -> colour scatter of
+// seg_plane::set_plane_color (/root/reference/tmc3/my_function.cpp:260-275).
+#include <climits>
+
+#include "bs_common.h"
+
+namespace bs {
+namespace {
+
+__global__ void minmax_kernel(const int32_t* __restrict__ xyz, int64_t n, int32_t* __restrict__ mn)
+{
+  int m[3] = {INT_MAX, INT_MAX, INT_MAX};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      m[a] = min(m[a], xyz[3 * i + a]);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+    for (int o = 32; o > 0; o >>= 1)
+      m[a] = min(m[a], __shfl_xor(m[a], o));
+  __shared__ int sm[3][4];
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      sm[a][threadIdx.x >> 6] = m[a];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int v = sm[threadIdx.x][0];
+    for (int t = 1; t < (int)(blockDim.x >> 6); t++)
+      v = min(v, sm[threadIdx.x][t]);
+    atomicMin(&mn[threadIdx.x], v);
+  }
+}
+
+__global__ void shift_kernel(int32_t* __restrict__ xyz, int64_t n3, const int32_t* __restrict__ mn)
+{
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n3)
+    xyz[i] -= mn[i % 3];  // pointCloud[i] -= box.min (TMC3.cpp:70-72)
+}
+
+__global__ void color_scatter_kernel(const PlaneRec* __restrict__ planes, const int32_t* __restrict__ list,
+                                     const int32_t* __restrict__ rgb, int64_t n, uint16_t* __restrict__ colors)
+{
+  const PlaneRec r = planes[blockIdx.x];
+  const uint16_t c0 = (uint16_t)rgb[3 * blockIdx.x], c1 = (uint16_t)rgb[3 * blockIdx.x + 1],
+                 c2 = (uint16_t)rgb[3 * blockIdx.x + 2];
+  for (int64_t t = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; t < r.list_n; t += (int64_t)gridDim.y * blockDim.x) {
+    const int64_t id = list[r.list_off + t];
+    if (id >= 0 && id < n) {
+      colors[3 * id] = c0;
+      colors[3 * id + 1] = c1;
+      colors[3 * id + 2] = c2;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace bs
+
+using namespace bs;
+
+extern "C" int bs_shift_to_origin_dev(bs_ctx* ctx, int32_t* d_xyz, int64_t n, int32_t* min_out)
+{
+  if (!ctx)
+    return BS_ERR_INVALID;
+  if (!d_xyz || n <= 0)
+    return fail(ctx, BS_ERR_INVALID, "null pointer or empty cloud");
+  BS_HIP(ctx, hipSetDevice(ctx->device));
+  BS_HIP(ctx, ctx->misc.reserve(256));
+  hipStream_t st = ctx->stream;
+  int32_t init[3] = {INT_MAX, INT_MAX, INT_MAX};
+  int32_t* d_mn = ctx->misc.as<int32_t>() + 48;
+  BS_HIP(ctx, hipMemcpyAsync(d_mn, init, sizeof init, hipMemcpyHostToDevice, st));
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 512);
+  minmax_kernel<<<blocks, 256, 0, st>>>(d_xyz, n, d_mn);
+  shift_kernel<<<(int)((3 * n + 255) / 256), 256, 0, st>>>(d_xyz, 3 * n, d_mn);
+  int32_t h[3];
+  BS_HIP(ctx, hipMemcpyAsync(h, d_mn, sizeof h, hipMemcpyDeviceToHost, st));
+  BS_HIP(ctx, hipStreamSynchronize(st));
+  BS_HIP(ctx, hipGetLastError());
+  if (min_out)
+    for (int a = 0; a < 3; a++)
+      min_out[a] = h[a];
+  ctx->order_n = 0;  // coordinates changed: a cached cell order no longer applies
+  return BS_OK;
+}
+
+extern "C" int bs_plane_colors_dev(bs_ctx* ctx, const int32_t* plane_rgb, int32_t n_planes, int64_t n,
+                                   uint16_t* d_colors)
+{
+  if (!ctx)
+    return BS_ERR_INVALID;
+  if (!d_colors || n <= 0 || (n_planes > 0 && !plane_rgb))
+    return fail(ctx, BS_ERR_INVALID, "null pointer");
+  if (!ctx->rg_valid || ctx->rg_n != n)
+    return fail(ctx, BS_ERR_INVALID, "no region-grow result for this cloud on the context");
+  BS_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  GrowStats hs;
+  BS_HIP(ctx, hipMemcpy(&hs, ctx->rg_stats.p, sizeof hs, hipMemcpyDeviceToHost));
+  if (hs.n_planes != n_planes)
+    return fail(ctx, BS_ERR_INVALID, "n_planes does not match the last region grow");
+  BS_HIP(ctx, hipMemsetAsync(d_colors, 0, sizeof(uint16_t) * 3 * n, st));  // my_function.cpp:262-264
+  if (n_planes > 0) {
+    BS_HIP(ctx, ctx->misc.reserve(256));
+    BS_HIP(ctx, ctx->fb_list.reserve(sizeof(int32_t) * (3 * (size_t)n_planes + 16)));
+    int32_t* d_rgb = ctx->fb_list.as<int32_t>();
+    BS_HIP(ctx, hipMemcpyAsync(d_rgb, plane_rgb, sizeof(int32_t) * 3 * n_planes, hipMemcpyHostToDevice, st));
+    color_scatter_kernel<<<dim3(n_planes, 16), 256, 0, st>>>(ctx->rg_planes.as<PlaneRec>(), ctx->rg_list.as<int32_t>(),
+                                                          d_rgb, n, d_colors);
+  }
+  BS_HIP(ctx, hipStreamSynchronize(st));
+  BS_HIP(ctx, hipGetLastError());
+  return BS_OK;
+}

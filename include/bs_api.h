@@ -168,6 +168,19 @@ int bs_region_grow_dev(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normal
 int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params* p,
                    int32_t* d_neigh, double* d_normals, int32_t* d_plane_idx);
 
+/* Pre-/post-processing either side of the path, on the device (SURVEY.md 8f-2,3).
+ *
+ * bs_shift_to_origin_dev: the buildingSeg constructor's bounding-box shift
+ * (TMC3.cpp:55-73): min over the cloud, then xyz -= min IN PLACE; min_out [3]
+ * (host, nullable) receives the subtracted minimum.  Synchronises.
+ *
+ * bs_plane_colors_dev: seg_plane::set_plane_color (my_function.cpp:260-275) for
+ * the planes of the last region grow on this context: d_colors [n][3] uint16
+ * (G,B,R slots) zeroed, then plane_rgb[p] (host, [n_planes][3]) scattered to
+ * every pointIdx entry of plane p. */
+int bs_shift_to_origin_dev(bs_ctx* ctx, int32_t* d_xyz, int64_t n, int32_t* min_out);
+int bs_plane_colors_dev(bs_ctx* ctx, const int32_t* plane_rgb, int32_t n_planes, int64_t n, uint16_t* d_colors);
+
 /* Copy the plane records of the last region-grow on this context to the host. */
 int bs_planes_fetch(bs_ctx* ctx, bs_planes* planes);
 

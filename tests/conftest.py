@@ -21,6 +21,15 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    # torch ships its own HIP runtime: when a test also needs torch device tensors,
+    # torch must initialise the GPU BEFORE libbuildingsegment_hip.so (linked against
+    # /opt/rocm) is loaded -- the same order bench.py uses
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
     from buildingsegment_amd import api
     ctx = api.Context(0)
     yield ctx

@@ -267,3 +267,30 @@ def test_bench_workload_facade_1m_full_parity(gpu_ctx, oracle):
     assert np.abs(np.linalg.norm(normals, axis=1) - 1).max() < 1e-12 and (normals[:, 2] >= 0).all()
     labelled = plane_idx[plane_idx > 0]
     assert labelled.max() <= len(planes) + 1 and (plane_idx != 0).all()
+
+
+def test_device_pre_and_post_processing(gpu_ctx, oracle):
+    """SURVEY 8f-2,3: bbox shift (buildingSeg ctor, TMC3.cpp:55-73) and colour
+    scatter (set_plane_color, my_function.cpp:260-275) on device-resident buffers."""
+    import torch
+    raw = synth.plane_cube()[:20000].astype(np.int64) + np.array([5000, -250, 77])
+    d_xyz = torch.from_numpy(raw.astype(np.int32)).cuda()
+    n = len(raw)
+    mn = gpu_ctx.shift_to_origin_dev(d_xyz.data_ptr(), n)
+    assert mn.tolist() == raw.min(0).tolist()
+    shifted = (raw - raw.min(0)).astype(np.int32)
+    assert np.array_equal(d_xyz.cpu().numpy(), shifted)
+    p = api.default_params(k=15)
+    d_plane = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu_ctx.segment_dev(d_xyz.data_ptr(), n, d_plane.data_ptr(), p)
+    planes = gpu_ctx.planes_fetch()
+    ng, nr = oracle.knn_normals(shifted, k=15)
+    opi, opl = oracle.region_grow(shifted, nr, ng)
+    assert np.array_equal(d_plane.cpu().numpy(), opi) and len(planes) == len(opl["id"])
+    rgb = np.arange(3 * len(planes), dtype=np.int32).reshape(-1, 3) + 60
+    d_col = torch.full((n, 3), 999, dtype=torch.int16, device="cuda")
+    gpu_ctx.plane_colors_dev(rgb, n, d_col.data_ptr())
+    want = np.zeros((n, 3), np.uint16)
+    for i, q in enumerate(planes):
+        want[q.pointIdx] = rgb[i]
+    assert np.array_equal(d_col.cpu().numpy().view(np.uint16), want)
