@@ -347,7 +347,11 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   const bool act = j < nc;
   const int32_t seed = cand[w];
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
-  int64_t ln = 1, sp = 0, lds_lo = 0, logn = 0, steps = 0, iters = 0;
+  // 32-bit bookkeeping (n < 2^31): 64-bit scalar arithmetic doubles the SALU work of every call
+  int ln = 1, sp = 0, lds_lo = 0, logn = 0;
+  int64_t steps = 0;
+  uint32_t iters = 0;
+  const uint32_t iter_cap = step_cap > 0xFFFFFFF0ll ? 0xFFFFFFF0u : (uint32_t)step_cap;
   int status = ST_DONE;
   // optimistic claims: the atomicMin of call i is only checked in call i+1,
   // after the next gather has been issued (its latency hides the atomic's)
@@ -373,16 +377,16 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     for (;;) {
       if (!have_child && sp == 0)
         break;
-      if (++iters > step_cap) {
+      if (++iters > iter_cap) {
         status = ST_WATCHDOG;
         break;
       }
       // ---- which pending call does my lane group evaluate? ----
       const int fs = have_child ? 1 : 0;              // first stack-fed group
-      const int64_t e = sp - 1 - (int64_t)(g - fs);   // LIFO entry of a stack-fed group
+      const int e = sp - 1 - (g - fs);                // LIFO entry of a stack-fed group
       const bool is_child = have_child && g == 0;
       const bool valid = is_child || (g >= fs && e >= 0);
-      const int ngv = fs + (int)((sp < (int64_t)(NG - fs)) ? sp : (int64_t)(NG - fs));  // valid groups
+      const int ngv = fs + ((sp < NG - fs) ? sp : NG - fs);  // valid groups
       int cand_id = 0;
       if (valid && act) {
         if (is_child)
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         else if (e >= lds_lo)
           cand_id = lds_stack[(e & (LDS_STACK - 1)) * KC + j + 1];
         else
-          cand_id = ld_i32(pool.base + stack.off + e * KC + j + 1);
+          cand_id = ld_i32(pool.base + stack.off + (int64_t)e * KC + j + 1);
       }
       const int killed = ld_i32(dead + seed);  // an earlier plane took one of my points: I am invalid
       int own = 0, tg = INF, px = 0, py = 0, pz = 0;
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       if (gstar < 0)
         continue;
       // ---- expand call gstar: :231-255 ----
-      if (!slab_ensure(pool, list, ln, ln + cnt, lane) || !slab_ensure(pool, stack, sp * KC, (sp + cnt) * KC, lane)) {
+      if (!slab_ensure(pool, list, ln, ln + cnt, lane) || !slab_ensure(pool, stack, (int64_t)sp * KC, (int64_t)(sp + cnt) * KC, lane)) {
         status = ST_NOMEM;
         break;
       }
@@ -543,8 +547,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
       // children 2..cnt go on the LIFO (reversed) with their rows; id in slot 0
       if (ok && rank > 0) {
-        const int64_t pe = sp + (cnt - 1 - rank);
-        int4* slot = reinterpret_cast<int4*>(pool.base + stack.off + pe * KC);
+        const int pe = sp + (cnt - 1 - rank);
+        int4* slot = reinterpret_cast<int4*>(pool.base + stack.off + (int64_t)pe * KC);
         int4* lslot = reinterpret_cast<int4*>(lds_stack + (pe & (LDS_STACK - 1)) * KC);
         row[0] = cand_id;
 #pragma unroll
