@@ -75,7 +75,9 @@ struct PlaneOut {
   int32_t status;
   int32_t keep;        // committed (list_n > th_count)
   int32_t consistent;  // set by validate2_kernel
-  int32_t pad;
+  int32_t pad;         // host command for plane_apply_kernel
+  int32_t thief;       // diagnostics: seed of the plane that took a point from this one (-1: none)
+  int32_t pad2;
 };
 
 struct Pool {
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       // settle last call's optimistic claims
       const bool lost = pend && pend_old <= seed;  // an earlier plane got there first (or a double claim)
       if (pend && pend_old > seed && pend_old != INF)
-        dead[pend_old] = 1;  // took it from a later plane: that plane is invalid
+        dead[pend_old] = seed + 1;  // took it from a later plane: that plane is invalid (value: thief + 1)
       pend = false;
       if (killed || __ballot(lost)) {
         status = ST_STOLEN;
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   if (status == ST_DONE) {
     const bool lost = pend && pend_old <= seed;
     if (pend && pend_old > seed && pend_old != INF)
-      dead[pend_old] = 1;
+      dead[pend_old] = seed + 1;
     if (__ballot(lost))
       status = ST_STOLEN;
   }
@@ -599,6 +601,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     o.keep = (status == ST_DONE && ln > a.th_count) ? 1 : 0;
     o.consistent = 0;
     o.pad = 0;
+    o.thief = ld_i32(dead + seed) - 1;
+    o.pad2 = 0;
     out[w] = o;
   }
 }
@@ -996,6 +1000,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
               "pending=%d (consistent %d) first_bad=%d new_min=%d maxsteps=%ld sumsteps=%ld maxlist=%ld passes=%ld\n",
               (long)rounds, F, ncand_all, ncand, cnt[ST_DONE], cons, cnt[ST_FAILED0], cnt[ST_NOMEM], cnt[ST_STOLEN],
               npend, pcons, first_bad, new_min, (long)maxsteps, (long)sumsteps, (long)maxlist, (long)passes);
+      if (getenv("BS_DEBUG_PLANES"))
+        for (int w = 0; w < ncand; w++)
+          fprintf(stderr, "[bs]   plane seed=%d status=%d consistent=%d steps=%ld list=%ld log=%ld thief=%d\n",
+                  h_out[w].seed, h_out[w].status, h_out[w].consistent, (long)h_out[w].steps, (long)h_out[w].list_n,
+                  (long)h_out[w].log_n, h_out[w].thief);
     }
     // merge pending and new planes in seed order: below first_bad -> final,
     // consistent ones above it stay pending, the rest is dropped from the structure
