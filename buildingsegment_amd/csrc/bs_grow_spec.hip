@@ -242,6 +242,27 @@ __global__ void pull_pass_kernel(int64_t n, int K, const uint32_t* __restrict__ 
   }
 }
 
+// BS_VERIFY=1: is (omega, occ) a fixed point of the owner equations?
+__global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ hmask, const uint8_t* __restrict__ ps,
+                                       const int32_t* __restrict__ base, const int32_t* __restrict__ roff,
+                                       const int32_t* __restrict__ radj, const int32_t* __restrict__ omega,
+                                       const uint8_t* __restrict__ occ, int* nbad)
+{
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= n)
+    return;
+  int32_t v = base[c];
+  for (int32_t e = roff[c]; e < roff[c + 1]; e++) {
+    const int32_t j = radj[e];
+    const bool oj = hmask[j] != 0 && !ps[j] && omega[j] >= j;
+    if (oj && j < v)
+      v = j;
+  }
+  const bool oc = hmask[c] != 0 && !ps[c] && omega[c] >= (int32_t)c;
+  if (v != omega[c] || (oc ? 1 : 0) != occ[c])
+    atomicAdd(nbad, 1);
+}
+
 // ---- plane-attempt candidates -------------------------------------------------
 __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
                                  int64_t n, int32_t F, const uint8_t* __restrict__ ps,
@@ -575,11 +596,15 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       have_child = true;
     }
   }
-  // claims of the very last call
+  // Settle the claims of the last call on EVERY exit path (normal end, failed
+  // depth 0, pool exhaustion, kill): a plane that took a point from a later
+  // plane must mark that plane invalid even if it does not survive itself --
+  // otherwise the victim could reclaim the point from this (dead) plane and end
+  // up holding it twice without ever being invalidated.
+  if (pend && pend_old > seed && pend_old != INF)
+    dead[pend_old] = seed + 1;
   if (status == ST_DONE) {
     const bool lost = pend && pend_old <= seed;
-    if (pend && pend_old > seed && pend_old != INF)
-      dead[pend_old] = seed + 1;
     if (__ballot(lost))
       status = ST_STOLEN;
   }
@@ -609,13 +634,14 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
 
 // every accepted point must still carry this plane's claim
 __global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
-                                                       int4* rec, int quads)
+                                                       int4* rec, int quads, const int32_t* __restrict__ dead, int64_t n)
 {
   const int w = blockIdx.x;
   if (w >= ncand || out[w].status != ST_DONE)
     return;
   const PlaneOut o = out[w];
-  bool bad = false;
+  // lost a point after it had finished, or an impossible list (each point at most once + the seed)
+  bool bad = dead[o.seed] != 0 || o.list_n > n + 1;
   for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64)
     bad = bad || *rec_tag(rec, quads, pool[o.list_off + t]) != o.seed;
   const unsigned long long b = __ballot(bad);
@@ -835,8 +861,18 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       BS_HIP(ctx, hipStreamSynchronize(st));
       passes++;
       std::swap(dcur, dnext);  // dcur now holds the newly dirtied points (the old dcur was cleared by the pass)
-      if (!any)
+      if (!any) {
+        if (getenv("BS_VERIFY")) {
+          BS_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, sizeof(int), st));
+          verify_fixpoint_kernel<<<nblk(n, 256), 256, 0, st>>>(n, hmask, ps, base, roff, radj, omega, occ, d_misc + 3);
+          int nb = 0;
+          BS_HIP(ctx, hipMemcpyAsync(&nb, d_misc + 3, sizeof nb, hipMemcpyDeviceToHost, st));
+          BS_HIP(ctx, hipStreamSynchronize(st));
+          if (nb)
+            fprintf(stderr, "[bs] VERIFY: owner structure is not a fixed point at %d points (pass %ld)\n", nb, (long)passes);
+        }
         return BS_OK;
+      }
     }
     return fail(ctx, BS_ERR_INTERNAL, "orphan fixed point did not converge");
   };
@@ -936,7 +972,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
-      validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, rec, quads);
+      validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n);
       // insert the finished planes and let the owners settle
       plane_apply_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
       rc = propagate();
@@ -968,6 +1004,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     bool nomem_lowest = false;
     for (int w = 0; w < ncand; w++) {
       const PlaneOut& o = h_out[w];
+      if (getenv("BS_DEBUG") && o.list_n > n + 1)
+        fprintf(stderr, "[bs] IMPOSSIBLE list: round %ld w=%d seed=%d status=%d consistent=%d list_n=%ld steps=%ld log=%ld thief=%d\n",
+                (long)rounds, w, o.seed, o.status, o.consistent, (long)o.list_n, (long)o.steps, (long)o.log_n, o.thief);
       if (o.status == ST_WATCHDOG)
         return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): watchdog");
       if (o.status == ST_DONE && !o.consistent)
@@ -1010,6 +1049,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // consistent ones above it stay pending, the rest is dropped from the structure
     std::vector<PlaneOut> next_pending;
     int finals = 0, dropped = 0;
+    int pend_room = MAX_PENDING;  // old pending planes that stay have priority over new ones
+    for (int w = 0; w < npend; w++)
+      pend_room -= (h_pend[w].consistent && h_pend[w].seed >= first_bad) ? 1 : 0;
     {
       int ip = 0, iw = 0;
       while (ip < npend || iw < ncand) {
@@ -1030,12 +1072,16 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         }
         if (o.seed < first_bad) {
           finals++;
+          if (getenv("BS_DEBUG") && o.keep)
+            fprintf(stderr, "[bs]   commit seed=%d n=%ld log=%ld steps=%ld from=%s round=%ld first_bad=%d\n", o.seed,
+                    (long)o.list_n, (long)o.log_n, (long)o.steps, take_p ? "pending" : "new", (long)rounds, first_bad);
           rc = commit_plane(o, src);
           if (rc != BS_OK)
             return rc;
         } else if (take_p) {
           next_pending.push_back(o);
-        } else if ((int)next_pending.size() < MAX_PENDING && pstore_top + o.list_n + o.log_n + 8 <= pstore_cap) {
+        } else if (pend_room > 0 && pstore_top + o.list_n + o.log_n + 8 <= pstore_cap) {
+          pend_room--;
           PlaneOut q = o;
           q.list_off = pstore_top;
           copies.push_back({pool.base + o.list_off, pstore + q.list_off, o.list_n});

@@ -294,3 +294,19 @@ def test_device_pre_and_post_processing(gpu_ctx, oracle):
     for i, q in enumerate(planes):
         want[q.pointIdx] = rgb[i]
     assert np.array_equal(d_col.cpu().numpy().view(np.uint16), want)
+
+
+def test_regression_fuzz_7_106_unsettled_claims(gpu_ctx, oracle):
+    """Found by tools/fuzz_parity.py: k=4, cos_th=0 on a curved sheet gives ~18 000
+    plane attempts (10 commit).  A plane that failed at depth 0 left its optimistic
+    claims unsettled, its victim reclaimed the point and held it twice while passing
+    validation.  Must be exact, repeatedly, at full concurrency."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "data", "fuzz_fail_7_106.npz"))
+    p = api.default_params(k=int(g["k"]), th_thickness=int(g["th"]), th_point_count=int(g["cnt"]),
+                           cos_th=float(g["cos"]), rg_mode=2)
+    opi, opl = oracle.region_grow(g["xyz"], g["normals"], g["neigh"], th_thickness=p.th_thickness,
+                                  th_point_count=p.th_point_count, cos_th=p.cos_th)
+    for _ in range(3):
+        pi, planes = gpu_ctx.region_grow(g["xyz"], g["normals"], g["neigh"], p)
+        assert np.array_equal(pi, opi)
+        assert [len(q.pointIdx) for q in planes] == np.diff(opl["offset"]).tolist()
