@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Full-size exactness check of a bench workload against the CPU oracle (GPU box;
+takes minutes: the oracle is single threaded).  usage: check_large.py <workload>"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from buildingsegment_amd import api  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+wl = sys.argv[1]
+xyz, k = bench.make_cloud(wl, 0)
+print(wl, "n", len(xyz), "k", k, flush=True)
+ctx = api.Context(0)
+t = time.time()
+neigh, normals, plane_idx, planes = ctx.segment(xyz, api.default_params(k=k))
+print("gpu segment (host buffers)", round(time.time() - t, 2), "s", ctx.timings(), flush=True)
+t = time.time()
+oneigh, onormals = O.knn_normals(xyz, k=k)
+print("oracle knn+normals", round(time.time() - t, 1), "s", flush=True)
+print("neigh equal", np.array_equal(neigh, oneigh), "normals equal", np.array_equal(normals, onormals), flush=True)
+t = time.time()
+opi, opl = O.region_grow(xyz, onormals, oneigh)
+print("oracle region grow", round(time.time() - t, 1), "s", flush=True)
+ok = np.array_equal(plane_idx, opi) and len(planes) == len(opl["id"])
+if ok and planes:
+    ok = np.array_equal(np.concatenate([q.pointIdx for q in planes]), opl["point_idx"]) and \
+        np.array_equal(np.stack([q.normal for q in planes]), opl["normal"]) and \
+        np.array_equal(np.stack([q.center for q in planes]), opl["center"])
+print("labels/planes equal", ok, "planes", len(planes), "labelled", int((plane_idx > 0).sum()), flush=True)
+sys.exit(0 if ok else 1)
