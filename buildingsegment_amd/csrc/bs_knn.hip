@@ -20,6 +20,8 @@
 // rings, or whose r-ball holds more than max_nn points (needs a top-max_nn
 // selection), are appended to a work list and finished by knn_general_kernel,
 // which keeps explicit sorted lists in scratch and falls back to a full scan.
+#include <cstdlib>
+
 #include "bs_common.h"
 #include "bs_normal.h"
 
@@ -170,6 +172,220 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
   if (!done || m.n > max_nn || kth_final == ~0ull) {
     const int slot = atomicAdd(fb_count, 1);
     fb_list[slot] = (int32_t)s;
+    return;
+  }
+  int32_t* row = neigh + (int64_t)(loc - q_begin) * K;
+#pragma unroll
+  for (int j = 0; j < KC; j++)
+    if (j < K)
+      row[j] = (int32_t)(uint32_t)best[j];
+  if (normals) {
+    const V3 nv = normal_from_moments(m);
+    double* o = normals + 3 * (int64_t)(loc - q_begin);
+    o[0] = nv.x;
+    o[1] = nv.y;
+    o[2] = nv.z;
+  }
+  if (cert_r2 && (kth_final >> 32) >= cert_r2)
+    atomicAdd(uncert, 1ull);
+}
+
+// ---- LDS-staged tile kernel ---------------------------------------------------------
+// One workgroup = 256 consecutive queries of the cell-sorted order (one compact
+// patch of space).  The union of the 27-cell neighbourhoods of the patch is staged
+// ONCE into LDS -- an LDS hash of the needed cells (filled by the first query of
+// every cell), one global table probe per distinct cell, then coalesced copies of
+// the cells' contiguous point runs -- and all 256 queries do rings 0..1 out of LDS.
+// Queries that need ring 2 continue from HBM/L2 inside the same thread; patches
+// whose neighbourhood does not fit the tile fall back to the untiled path.
+constexpr int TILE_PTS = 3072;    // 48 KB of int4
+constexpr int TILE_HASH = 1024;   // distinct cells per patch (open addressing)
+
+struct TileCell {
+  unsigned long long key;  // packed cell coords, ~0 = free slot
+  int32_t off;             // first point in the tile, -1: cell is empty in the cloud
+  int32_t cnt;
+};
+
+template <int KC>
+__device__ __forceinline__ void knn_consider(const int4 c, const int q[3], double r2, uint64_t (&best)[KC], Moments& m)
+{
+  const int ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
+  const uint32_t d2 = (uint32_t)(ex * ex) + (uint32_t)(ey * ey) + (uint32_t)(ez * ez);
+  uint64_t key = ((uint64_t)d2 << 32) | (uint32_t)c.w;
+  if (key < best[KC - 1]) {
+#pragma unroll
+    for (int j = 0; j < KC; j++) {
+      const bool lt = key < best[j];
+      const uint64_t hi = lt ? best[j] : key;
+      best[j] = lt ? key : best[j];
+      key = hi;
+    }
+  }
+  if ((double)d2 < r2)
+    moments_add(m, c.x, c.y, c.z);
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void knn_tile_kernel(GridDev g, int64_t q_begin, int64_t q_end, int K, int max_nn,
+                                                       double r2, int32_t* __restrict__ neigh,
+                                                       double* __restrict__ normals, int32_t* __restrict__ fb_list,
+                                                       int32_t* __restrict__ fb_count, uint64_t cert_r2,
+                                                       unsigned long long* __restrict__ uncert)
+{
+  __shared__ int4 tile[TILE_PTS];
+  __shared__ TileCell th[TILE_HASH];
+  __shared__ int32_t th_gstart[TILE_HASH];
+  __shared__ unsigned long long skey[256];
+  __shared__ int tile_n, overflow;
+  const int tid = threadIdx.x;
+  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + tid;
+  const bool inb = s < g.n;
+  int4 P = make_int4(0, 0, 0, 0);
+  int32_t loc = -1;
+  if (inb) {
+    P = g.spts[s];
+    loc = g.slocal[s];
+  }
+  const int q[3] = {P.x, P.y, P.z};
+  const int ci[3] = {(int)((uint32_t)(P.x - g.mn[0]) / (uint32_t)g.cell),
+                     (int)((uint32_t)(P.y - g.mn[1]) / (uint32_t)g.cell),
+                     (int)((uint32_t)(P.z - g.mn[2]) / (uint32_t)g.cell)};
+  const bool isq = inb && loc >= q_begin && loc < q_end;
+  for (int i = tid; i < TILE_HASH; i += 256) {
+    th[i].key = ~0ull;
+    th[i].off = -1;
+    th[i].cnt = 0;
+  }
+  if (tid == 0) {
+    tile_n = 0;
+    overflow = 0;
+  }
+  skey[tid] = isq ? pack_cell((uint32_t)ci[0], (uint32_t)ci[1], (uint32_t)ci[2]) : ~0ull;
+  __syncthreads();
+  // 1. the first query of every cell registers the 27 cells it needs
+  if (isq && (tid == 0 || skey[tid - 1] != skey[tid])) {
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          const int cx = ci[0] + dx, cy = ci[1] + dy, cz = ci[2] + dz;
+          if (cx < 0 || cy < 0 || cz < 0 || cx >= g.dim[0] || cy >= g.dim[1] || cz >= g.dim[2])
+            continue;
+          const unsigned long long k = pack_cell((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);
+          uint32_t h = hash_cell(k) & (TILE_HASH - 1);
+          int probes = 0;
+          for (;;) {
+            const unsigned long long prev = atomicCAS(&th[h].key, ~0ull, k);
+            if (prev == ~0ull || prev == k)
+              break;
+            h = (h + 1) & (TILE_HASH - 1);
+            if (++probes >= TILE_HASH - 1) {
+              overflow = 1;
+              break;
+            }
+          }
+        }
+  }
+  __syncthreads();
+  // 2. one global table probe per distinct cell; reserve its run in the tile
+  for (int i = tid; i < TILE_HASH; i += 256) {
+    const unsigned long long k = th[i].key;
+    if (k == ~0ull)
+      continue;
+    int cs, ce;
+    if (cell_lookup(g, (uint32_t)(k & 0x1FFFFF), (uint32_t)((k >> 21) & 0x1FFFFF), (uint32_t)(k >> 42), cs, ce)) {
+      const int cnt = ce - cs;
+      const int off = atomicAdd(&tile_n, cnt);
+      if (off + cnt > TILE_PTS) {
+        overflow = 1;
+      } else {
+        th[i].off = off;
+        th[i].cnt = cnt;
+        th_gstart[i] = cs;
+      }
+    }
+  }
+  __syncthreads();
+  const bool tiled = overflow == 0;
+  // 3. coalesced copies of the cells' point runs (16 lanes per cell)
+  if (tiled) {
+    const int grp = tid >> 4, gl = tid & 15;
+    for (int i = grp; i < TILE_HASH; i += 16) {
+      const int cnt = th[i].cnt;
+      if (cnt <= 0)
+        continue;
+      const int off = th[i].off, gs = th_gstart[i];
+      for (int j = gl; j < cnt; j += 16)
+        tile[off + j] = g.spts[gs + j];
+    }
+  }
+  __syncthreads();
+  if (!isq)
+    return;
+  uint64_t best[KC];
+#pragma unroll
+  for (int j = 0; j < KC; j++)
+    best[j] = ~0ull;
+  Moments m = {};
+  bool done = false;
+  for (int rho = 0; rho <= BS_FAST_RINGS && !done; rho++) {
+    for (int dz = -rho; dz <= rho; dz++) {
+      const int cz = ci[2] + dz;
+      if (cz < 0 || cz >= g.dim[2])
+        continue;
+      for (int dy = -rho; dy <= rho; dy++) {
+        const int cy = ci[1] + dy;
+        if (cy < 0 || cy >= g.dim[1])
+          continue;
+        const bool face = (dz == -rho || dz == rho || dy == -rho || dy == rho);
+        const int step = face ? 1 : (rho > 0 ? 2 * rho : 1);
+        for (int dx = -rho; dx <= rho; dx += step) {
+          const int cx = ci[0] + dx;
+          if (cx < 0 || cx >= g.dim[0])
+            continue;
+          // one candidate loop for both sources (a second copy of the sorted
+          // insertion network would double the register footprint)
+          int off = 0, cnt = 0;
+          const bool from_lds = tiled && rho <= 1;
+          if (from_lds) {
+            const unsigned long long k = pack_cell((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);
+            uint32_t h = hash_cell(k) & (TILE_HASH - 1);
+            while (th[h].key != k)  // registered in step 1: always found
+              h = (h + 1) & (TILE_HASH - 1);
+            off = th[h].off;
+            cnt = th[h].cnt;
+          } else {
+            int cs, ce;
+            if (cell_lookup(g, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce)) {
+              off = cs;
+              cnt = ce - cs;
+            }
+          }
+          for (int t = 0; t < cnt; t++) {
+            const int4 c = from_lds ? tile[off + t] : g.spts[off + t];
+            knn_consider<KC>(c, q, r2, best, m);
+          }
+        }
+      }
+    }
+    uint64_t R2;
+    const bool bounded = guaranteed_radius(g, q, ci, rho, R2);
+    if (!bounded) {
+      done = true;
+    } else {
+      uint64_t kth = ~0ull;
+#pragma unroll
+      for (int j = 0; j < KC; j++)
+        kth = (j == K - 1) ? best[j] : kth;
+      done = kth != ~0ull && (kth >> 32) < R2 && (double)R2 >= r2;
+    }
+  }
+  uint64_t kth_final = ~0ull;
+#pragma unroll
+  for (int j = 0; j < KC; j++)
+    kth_final = (j == K - 1) ? best[j] : kth_final;
+  if (!done || m.n > max_nn || kth_final == ~0ull) {
+    fb_list[atomicAdd(fb_count, 1)] = (int32_t)s;
     return;
   }
   int32_t* row = neigh + (int64_t)(loc - q_begin) * K;
@@ -364,12 +580,22 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
   // fast kernel needs every candidate d^2 < 2^32
   const bool fast_ok = (int64_t)g.cell * (2 * BS_FAST_RINGS + 1) <= 37500;
   if (fast_ok) {
-    if (p.k <= 16)
-      knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                  fb_list, fb_count, cert_r2, uncert);
-    else
-      knn_fast_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                  fb_list, fb_count, cert_r2, uncert);
+    const bool untiled = getenv("BS_KNN_UNTILED") != nullptr;
+    if (p.k <= 16) {
+      if (untiled)
+        knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                    fb_list, fb_count, cert_r2, uncert);
+      else
+        knn_tile_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                    fb_list, fb_count, cert_r2, uncert);
+    } else {
+      if (untiled)
+        knn_fast_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                    fb_list, fb_count, cert_r2, uncert);
+      else
+        knn_tile_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                    fb_list, fb_count, cert_r2, uncert);
+    }
   } else {
     mark_all_kernel<<<blocks, 256, 0, st>>>(g, q_begin, q_end, fb_list, fb_count);
   }

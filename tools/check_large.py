@@ -21,7 +21,14 @@ t = time.time()
 neigh, normals, plane_idx, planes = ctx.segment(xyz, api.default_params(k=k))
 print("gpu segment (host buffers)", round(time.time() - t, 2), "s", ctx.timings(), flush=True)
 t = time.time()
-oneigh, onormals = O.knn_normals(xyz, k=k)
+n = len(xyz)
+oneigh = np.empty((n, k), np.int32)
+onormals = np.empty((n, 3), np.float64)
+chunk = 4_000_000  # progress lines keep the GPU box's silence watchdog quiet
+for q0 in range(0, n, chunk):
+    q1 = min(n, q0 + chunk)
+    oneigh[q0:q1], onormals[q0:q1] = O.knn_normals(xyz, k=k, q0=q0, q1=q1)
+    print("  oracle knn+normals", q1, "/", n, round(time.time() - t, 1), "s", flush=True)
 print("oracle knn+normals", round(time.time() - t, 1), "s", flush=True)
 print("neigh equal", np.array_equal(neigh, oneigh), "normals equal", np.array_equal(normals, onormals), flush=True)
 t = time.time()
