@@ -198,6 +198,11 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
 // the cells' contiguous point runs -- and all 256 queries do rings 0..1 out of LDS.
 // Queries that need ring 2 continue from HBM/L2 inside the same thread; patches
 // whose neighbourhood does not fit the tile fall back to the untiled path.
+// Bit-identical to knn_fast_kernel (same parity tests), but MEASURED SLOWER on
+// MI355X (1 M points k=16: 1.00 vs 0.58 ms; 50 M: 51.7 vs 24.3 ms): the cell-sorted
+// order already makes L1/L2 serve the candidates, while staging costs LDS atomics,
+// three barriers and drops occupancy to 2 waves/SIMD (70 KB LDS per workgroup).
+// Kept as an opt-in (BS_KNN_TILED=1) for data sets where the caches lose.
 constexpr int TILE_PTS = 3072;    // 48 KB of int4
 constexpr int TILE_HASH = 1024;   // distinct cells per patch (open addressing)
 
@@ -580,7 +585,9 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
   // fast kernel needs every candidate d^2 < 2^32
   const bool fast_ok = (int64_t)g.cell * (2 * BS_FAST_RINGS + 1) <= 37500;
   if (fast_ok) {
-    const bool untiled = getenv("BS_KNN_UNTILED") != nullptr;
+    // measured on MI355X: the LDS-staged variant is slower than the cache-served one
+    // (1 M: 1.00 vs 0.58 ms, 50 M: 51.7 vs 24.3 ms) -- opt-in only
+    const bool untiled = getenv("BS_KNN_TILED") == nullptr;
     if (p.k <= 16) {
       if (untiled)
         knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
