@@ -45,7 +45,7 @@ namespace bs {
 namespace {
 
 constexpr int32_t INF = 0x7fffffff;
-constexpr int MAX_WAVES = 4096;  // upper bound of plane attempts grown concurrently per round
+constexpr int MAX_WAVES = 16384;  // upper bound of plane attempts grown concurrently per round
 constexpr int MAX_PENDING = 4096;  // finished planes waiting for earlier attempts
 
 enum : int32_t { ST_NONE = 0, ST_DONE = 1, ST_FAILED0 = 2, ST_NOMEM = 3, ST_WATCHDOG = 4, ST_STOLEN = 5 };
@@ -766,8 +766,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int64_t list_cap = 2 * n + 64;
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;
   // round pool: lists + stacks + logs of every concurrent attempt
+  // concurrent plane attempts per round: more waves let late-index planes start in earlier rounds
+  int max_waves = 8192;
+  if (const char* e = getenv("BS_MAX_WAVES"))
+    max_waves = atoi(e);
+  max_waves = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(max_waves, MAX_WAVES), n / 8 + 64));
   const unsigned long long pool_cap = (unsigned long long)std::max<int64_t>(
-      std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * 32) * 2 * MAX_WAVES);
+      std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * 32) * 2 * max_waves);
   BS_HIP(ctx, ctx->rg_list.reserve(sizeof(int32_t) * list_cap));
   BS_HIP(ctx, ctx->rg_planes.reserve(sizeof(PlaneRec) * planes_cap));
   BS_HIP(ctx, ctx->rg_stats.reserve(sizeof(GrowStats)));
@@ -936,9 +941,6 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     copies.clear();
     return BS_OK;
   };
-  int max_waves = 2048;
-  if (const char* e = getenv("BS_MAX_WAVES"))
-    max_waves = std::max(1, std::min(MAX_WAVES, atoi(e)));
   for (;;) {
     rounds++;
     a.F = F;
