@@ -338,6 +338,9 @@ __global__ void refresh_records_kernel(const int32_t* __restrict__ omega, int4* 
 }
 
 constexpr int LDS_STACK = 256;  // LIFO entries (with rows) kept in LDS
+constexpr int MAX_RETRY = 12;    // in-launch re-growths of a plane that lost a point ...
+constexpr int RETRY_MAX_LIST = 16384;  // ... as long as little work is thrown away (long planes wait for the next
+                                      // round: their logged assumptions rarely survive their neighbours' insertion)
 
 // Step engine.
 //  * Every lane that gathers a neighbour gets that neighbour's own row with it
@@ -355,7 +358,7 @@ constexpr int LDS_STACK = 256;  // LIFO entries (with rows) kept in LDS
 template <int KC>
 __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t* __restrict__ cand, int ncand,
                                                        int4* rec, int32_t* dead, Pool pool,
-                                                       PlaneOut* __restrict__ out, int64_t step_cap)
+                                                       PlaneOut* __restrict__ out, int64_t step_cap, int retry_max_list)
 {
   __shared__ __attribute__((aligned(16))) int lds_stack[LDS_STACK * KC];
   constexpr int Q = RecLayout<KC>::QUADS;
@@ -382,12 +385,37 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   int pend_old = INF;
   const int4* srec = rec + (int64_t)seed * Q;
   const int4 s0 = srec[0], s1 = srec[1], s2 = srec[2];
-  double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z), cnz = __hiloint2double(s2.y, s2.x);
-  int ccx = s0.x, ccy = s0.y, ccz = s0.z;
-  double Sx = 0.0 + cnx, Sy = 0.0 + cny, Sz = 0.0 + cnz;
-  uint32_t Cx = (uint32_t)ccx, Cy = (uint32_t)ccy, Cz = (uint32_t)ccz;
-  if (!slab_ensure(pool, list, 0, 2048, lane) || !slab_ensure(pool, stack, 0, 256 * (int64_t)KC, lane) ||
-      !slab_ensure(pool, log, 0, 2048, lane)) {
+  double cnx, cny, cnz, Sx, Sy, Sz;
+  int ccx, ccy, ccz;
+  uint32_t Cx, Cy, Cz;
+  const bool have_mem = slab_ensure(pool, list, 0, 2048, lane) && slab_ensure(pool, stack, 0, 256 * (int64_t)KC, lane) &&
+                        slab_ensure(pool, log, 0, 2048, lane);
+  // A plane that loses a point to a sequentially earlier plane is invalid, but the
+  // earlier plane's claims are visible: instead of waiting for the next round the
+  // wave releases its claims and grows the plane again at once, now treating the
+  // earlier plane's points as taken (logged assumptions, validated after the round).
+  // Chains of planes that depend on each other thus resolve inside ONE launch.
+  for (int attempt = 0;; attempt++) {
+  status = ST_DONE;
+  pend = false;
+  pend_old = INF;
+  ln = 1;
+  sp = 0;
+  lds_lo = 0;
+  logn = 0;
+  cnx = __hiloint2double(s1.y, s1.x);
+  cny = __hiloint2double(s1.w, s1.z);
+  cnz = __hiloint2double(s2.y, s2.x);
+  ccx = s0.x;
+  ccy = s0.y;
+  ccz = s0.z;
+  Sx = 0.0 + cnx;
+  Sy = 0.0 + cny;
+  Sz = 0.0 + cnz;
+  Cx = (uint32_t)ccx;
+  Cy = (uint32_t)ccy;
+  Cz = (uint32_t)ccz;
+  if (!have_mem) {
     status = ST_NOMEM;
   } else {
     if (lane == 0)
@@ -608,6 +636,14 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     if (__ballot(lost))
       status = ST_STOLEN;
   }
+  if (status != ST_STOLEN || attempt >= MAX_RETRY || ln > retry_max_list)
+    break;
+  // release this incarnation's claims (points taken over by others keep their new tag) ...
+  for (int t = 1 + lane; t < ln; t += 64)
+    atomicCAS(rec_tag(rec, Q, ld_i32(pool.base + list.off + t)), seed, INF);
+  // ... and come back to life: marks written from here on concern the new incarnation
+  __hip_atomic_store(dead + seed, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }  // attempt loop
   if (lane == 0) {
     PlaneOut o;
     o.normal[0] = cnx;
@@ -767,6 +803,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;
   // round pool: lists + stacks + logs of every concurrent attempt
   // concurrent plane attempts per round: more waves let late-index planes start in earlier rounds
+  int retry_max_list = RETRY_MAX_LIST;
+  if (const char* e = getenv("BS_RETRY_MAX_LIST"))
+    retry_max_list = atoi(e);
   int max_waves = 8192;
   if (const char* e = getenv("BS_MAX_WAVES"))
     max_waves = atoi(e);
@@ -968,9 +1007,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
       (void)hipEventRecord(ctx->ev[6], st);
       if (KC == 16)
-        grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
+        grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, retry_max_list);
       else
-        grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096);
+        grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, retry_max_list);
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
