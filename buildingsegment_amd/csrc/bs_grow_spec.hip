@@ -450,10 +450,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       const int killed = ld_i32(dead + seed);  // an earlier plane took one of my points: I am invalid
       int own = 0, tg = INF, px = 0, py = 0, pz = 0;
       double mx = 0, my = 0, mz = 0;
-      int row[KC];
-#pragma unroll
-      for (int t = 0; t < KC; t++)
-        row[t] = 0;
+      int row[KC];  // only read from lanes that loaded it (the accepting lanes)
       if (valid && act) {
         const int4* r = rec + (int64_t)cand_id * Q;
         const int4 q0 = r[0], q1 = r[1], q2 = r[2];
@@ -500,7 +497,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       unsigned long long am = 0;
       int gstar = -1;
       bool ok = false;
-      for (int gg = 0; gg < ngv; gg++) {
+      for (int gg = 0; cm != 0 && gg < ngv; gg++) {  // cm == 0: every pending call is empty
         const unsigned long long gm = gmask0 << (gg * KC);
         if (cm & gm) {
           // Claim protocol for call gg.  tag[p] = seed of the in-flight plane
