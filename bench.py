@@ -9,8 +9,10 @@ With --gpus N every rank segments its own facade (independent objects, no
 data-path collective): weak scaling.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-``roofline`` (dominant kernel, HIP-event timed on the launch stream) and
-``cpu_baseline`` (the CPU oracle timed on this box's host cores, N=1 only).
+``roofline`` (dominant kernel, HIP-event timed on the launch stream),
+``cpu_baseline`` (the CPU oracle timed on this box's host cores, N=1 only) and
+``secondary`` (configs[2], the 10 M-point urban block at k=32, measured live the
+same way: the multi-plane regime; `--secondary ''` skips it).
 """
 from __future__ import annotations
 
@@ -38,6 +40,8 @@ def parse():
     ap.add_argument("--k", type=int, default=0, help="neighbour-list length (0 = workload default)")
     ap.add_argument("--rg-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", default="urban_10m",
+                    help="second workload measured live and reported under 'secondary' ('' = none)")
     return ap.parse_args()
 
 
@@ -208,6 +212,41 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(xyz, k)
+    # Secondary workload, measured live with the same barrier/timing protocol: BASELINE.json
+    # configs[2] (10 M-point urban block, k=32) shows the multi-plane regime of stage 3, which
+    # the single-surface facade cannot (its large planes form one dependency chain).
+    if args.secondary and args.secondary != args.workload:
+        del d_xyz, d_neigh, d_normals, d_plane
+        torch.cuda.empty_cache()
+        xyz2, k2 = make_cloud(args.secondary, rank)
+        n2 = len(xyz2)
+        p2 = api.default_params(k=k2, rg_mode=args.rg_mode)
+        e_xyz = torch.from_numpy(xyz2).to(dev)
+        e_neigh = torch.empty((n2, k2), dtype=torch.int32, device=dev)
+        e_normals = torch.empty((n2, 3), dtype=torch.float64, device=dev)
+        e_plane = torch.empty((n2,), dtype=torch.int32, device=dev)
+
+        def step2():
+            ctx.segment_dev(e_xyz.data_ptr(), n2, e_plane.data_ptr(), p2, e_neigh.data_ptr(), e_normals.data_ptr())
+
+        step2()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step2()
+        fence()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        tm2 = ctx.timings()
+        if rank == 0:
+            out["secondary"] = {"workload": args.secondary, "points_per_gpu": n2, "k": k2, "steps": 2, "warmup": 1,
+                                "value": world * n2 * 2 / el2 / 1e6, "unit": "Mpoints/s", "ms_per_step": el2 / 2 * 1e3,
+                                "grid_ms": tm2["grid_ms"], "knn_ms": tm2["knn_ms"], "grow_ms": tm2["grow_ms"],
+                                "rg_rounds": tm2["rg_rounds"], "largest_plane": tm2["largest_plane"]}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
