@@ -14,8 +14,10 @@
 //      {c in H(i) : c still free}.  With owner[p] := index of the attempt that
 //      keeps p labelled, the orphan makers obey
 //          owner[c] = min{ i : c in H(i), attempt i happens (owner[i] >= i) },
-//      a monotone system over lower indices only -> solved by Jacobi passes
-//      (orphan_pass_kernel) to its unique fixed point.
+//      a triangular system (only lower indices matter) with a unique fixed
+//      point.  It is kept up to date dynamically: reverse lists R(c) of the
+//      static masks are built once and pull_pass_kernel re-evaluates only the
+//      points dirtied by an inserted / dropped plane until nothing flips.
 //  (b) A plane attempt (all K-1 neighbours free and in H) is rare.  The lowest
 //      candidates are grown CONCURRENTLY, one wavefront each, against the
 //      tentative owner array; points are claimed with atomicMin(seed) so the
@@ -27,7 +29,10 @@
 //      attempt).  Everything below the first invalid or newly appearing
 //      candidate is FINAL -- identical to the sequential execution by
 //      induction over the seed index.  The lowest candidate of a round always
-//      validates, so every round makes progress.
+//      validates, so every round makes progress.  Consistent planes above that
+//      point stay "pending" (kept in the owner structure, re-validated every
+//      round, never grown again unless invalidated); short planes that lose a
+//      point re-grow inside the same launch.
 //
 // Final labels: plane_idx[p] = 1 + #(committed planes with seed < owner[p])
 // (cur_planeId only advances on commit, :199-202), -1 if owner[p] is none.
@@ -60,7 +65,7 @@ struct SpecArgs {
   double cos_th;
   int64_t th_count;
   int32_t F;  // every attempt < F is final
-  int32_t vec;  // neighbour rows are 16-byte aligned: int4 row loads/stores
+  int32_t pad;
 };
 
 struct PlaneOut {
@@ -852,7 +857,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   a.cos_th = p.cos_th;
   a.th_count = p.th_point_count;
   a.F = 0;
-  a.vec = 0;
+  a.pad = 0;
 
   const int KC = K <= 16 ? 16 : 32;
   const int quads = 4 + KC / 4;
