@@ -388,6 +388,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   // after the next gather has been issued (its latency hides the atomic's)
   bool pend = false;
   int pend_old = INF;
+  bool need_state = false;
   const int4* srec = rec + (int64_t)seed * Q;
   const int4 s0 = srec[0], s1 = srec[1], s2 = srec[2];
   double cnx, cny, cnz, Sx, Sy, Sz;
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     bool have_child = true;
     int child_cand = (g == 0 && act) ? reinterpret_cast<const int32_t*>(srec + 4)[j + 1] : 0;
     bool depth0 = true;
+    need_state = false;
     for (;;) {
       if (!have_child && sp == 0)
         break;
@@ -475,6 +477,21 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
           row[t + 2] = v.z;
           row[t + 3] = v.w;
         }
+      }
+      // The plane state of the previous expansion (square root, three f64 divisions,
+      // three 64-bit integer divisions) is evaluated HERE, between the issue of the
+      // gather loads above and their first use below: ~500 cycles of arithmetic
+      // that hide behind the memory latency instead of preceding it.
+      if (need_state) {
+        const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+        cnx = Sx / nrm;
+        cny = Sy / nrm;
+        cnz = Sz / nrm;
+        const uint64_t dn = (uint64_t)ln;
+        ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);  // int /= size_t (quirk Q3)
+        ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
+        ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
+        need_state = false;
       }
       bool geo = false;
       if (valid && act && tg != seed) {  // tg == seed: already labelled by this plane
@@ -590,14 +607,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         Cz += (uint32_t)readlane_i32(pz, l);
       }
       ln += cnt;
-      const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
-      cnx = Sx / nrm;
-      cny = Sy / nrm;
-      cnz = Sz / nrm;
-      const uint64_t dn = (uint64_t)ln;
-      ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);
-      ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
-      ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
+      need_state = true;  // :249-250 evaluated after the next gather has been issued
       // children 2..cnt go on the LIFO (reversed) with their rows; id in slot 0
       if (ok && rank > 0) {
         const int pe = sp + (cnt - 1 - rank);
@@ -625,6 +635,17 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       child_cand = nxt;
       have_child = true;
     }
+  }
+  if (need_state) {  // state of the very last expansion (the plane's reported normal / centre)
+    const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+    cnx = Sx / nrm;
+    cny = Sy / nrm;
+    cnz = Sz / nrm;
+    const uint64_t dn = (uint64_t)ln;
+    ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);
+    ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
+    ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
+    need_state = false;
   }
   // Settle the claims of the last call on EVERY exit path (normal end, failed
   // depth 0, pool exhaustion, kill): a plane that took a point from a later
