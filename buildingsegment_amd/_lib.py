@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbuildingsegment_hip.so")
+# BS_LIB_PATH: developer override (A/B runs of two builds of the same HIP library on one box)
+LIB_PATH = os.environ.get("BS_LIB_PATH") or os.path.join(HERE, "libbuildingsegment_hip.so")
 
 BS_OK = 0
 STATUS = {0: "BS_OK", -1: "BS_ERR_INVALID", -2: "BS_ERR_RANGE", -3: "BS_ERR_NOMEM", -4: "BS_ERR_HIP",

@@ -343,16 +343,21 @@ __global__ void refresh_records_kernel(const int32_t* __restrict__ omega, int4* 
 }
 
 constexpr int LDS_STACK = 256;  // LIFO entries (with rows) kept in LDS
+constexpr int LDS_REFILL = 128;  // entries brought back from HBM when the pops reach below the window
 constexpr int MAX_RETRY = 12;    // in-launch re-growths of a plane that lost a point ...
 constexpr int RETRY_MAX_LIST = 16384;  // ... as long as little work is thrown away (long planes wait for the next
                                       // round: their logged assumptions rarely survive their neighbours' insertion)
 
 // Step engine.
 //  * Every lane that gathers a neighbour gets that neighbour's own row with it
-//    (same cache line), so the next Broad() call (first accepted child) starts
-//    from registers; the other accepted children go on the LIFO with their rows
-//    (id in slot 0).  The top LDS_STACK entries of the LIFO live in LDS
-//    (write-through to the HBM slab): a pop is an LDS read.
+//    (same cache line); accepted children go on the LIFO with their rows (id in
+//    slot 0).  The top LDS_STACK entries of the LIFO live in LDS (write-through to
+//    the HBM slab, except the top entry, which the next call always consumes): a
+//    pop is ONE LDS read per lane, and when the pops reach below the window it is
+//    refilled from HBM (LDS_REFILL entries).  The kernel is bound by the
+//    instruction issue of single waves (in-kernel cycle probes: the gather's
+//    latency is fully hidden behind the plane-state arithmetic), so the hot loop
+//    avoids per-lane select chains and everything else that costs scalar registers.
 //  * Multi-pop: 64 % of all Broad() calls accept nothing, in long runs (DFS
 //    backtracking).  A call that accepts nothing changes neither the plane
 //    state nor any label, so the NEXT pending call sees exactly the same world:
@@ -426,39 +431,43 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   } else {
     if (lane == 0)
       pool.base[list.off] = seed;
-    // the call that continues from registers (first accepted child); at the
-    // start it is Broad(seed, 0)
-    bool have_child = true;
-    int child_cand = (g == 0 && act) ? reinterpret_cast<const int32_t*>(srec + 4)[j + 1] : 0;
+    // every pending call is a LIFO entry (id + row) in the LDS window; at the start
+    // the only entry is Broad(seed, 0)
+    if (lane < KC)
+      lds_stack[lane] = reinterpret_cast<const int32_t*>(srec + 4)[lane];
+    sp = 1;
     bool depth0 = true;
     need_state = false;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (;;) {
-      if (!have_child && sp == 0)
+      if (sp == 0)
         break;
       if (++iters > iter_cap) {
         status = ST_WATCHDOG;
         break;
       }
       // ---- which pending call does my lane group evaluate? ----
-      const int fs = have_child ? 1 : 0;              // first stack-fed group
-      const int e = sp - 1 - (g - fs);                // LIFO entry of a stack-fed group
-      const bool is_child = have_child && g == 0;
-      const bool valid = is_child || (g >= fs && e >= 0);
-      const int ngv = fs + ((sp < NG - fs) ? sp : NG - fs);  // valid groups
-      int cand_id = 0;
-      if (valid && act) {
-        if (is_child)
-          cand_id = child_cand;
-        else if (e >= lds_lo)
-          cand_id = lds_stack[(e & (LDS_STACK - 1)) * KC + j + 1];
-        else
-          cand_id = ld_i32(pool.base + stack.off + (int64_t)e * KC + j + 1);
+      const int e = sp - 1 - g;                       // LIFO entry of my group
+      const bool valid = e >= 0;
+      const int ngv = (sp < NG) ? sp : NG;            // valid groups
+      const int need_lo = (sp - NG > 0) ? sp - NG : 0;
+      if (need_lo < lds_lo) {  // wave-uniform
+        const int new_lo = lds_lo > LDS_REFILL ? lds_lo - LDS_REFILL : 0;
+        const int nw = (lds_lo - new_lo) * KC;
+        for (int t = lane; t < nw; t += 64) {
+          const int ee = new_lo + t / KC;
+          lds_stack[(ee & (LDS_STACK - 1)) * KC + (t % KC)] = ld_i32(pool.base + stack.off + (int64_t)new_lo * KC + t);
+        }
+        lds_lo = new_lo;
       }
+      int cand_id = 0;
+      if (valid && act)
+        cand_id = lds_stack[(e & (LDS_STACK - 1)) * KC + j + 1];
       const int killed = ld_i32(dead + seed);  // an earlier plane took one of my points: I am invalid
       int own = 0, tg = INF, px = 0, py = 0, pz = 0;
       double mx = 0, my = 0, mz = 0;
       int row[KC];  // only read from lanes that loaded it (the accepting lanes)
-      if (valid && act) {
+      {
         const int4* r = rec + (int64_t)cand_id * Q;
         const int4 q0 = r[0], q1 = r[1], q2 = r[2];
         tg = ld_i32(reinterpret_cast<const int32_t*>(r + 2) + 2);
@@ -581,8 +590,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       }
       depth0 = false;
       // pops: every consumed stack-fed call (the expanded one included)
-      sp -= (last + 1 - fs);
-      have_child = false;
+      sp -= last + 1;
       if (sp < lds_lo)
         lds_lo = sp;  // entries below are only in HBM; new pushes land in LDS again
       if (gstar < 0)
@@ -608,32 +616,26 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       }
       ln += cnt;
       need_state = true;  // :249-250 evaluated after the next gather has been issued
-      // children 2..cnt go on the LIFO (reversed) with their rows; id in slot 0
-      if (ok && rank > 0) {
+      // the children go on the LIFO (reversed) with their rows; id in slot 0.  The
+      // first child (top entry) is consumed by the very next call and therefore
+      // never needs its write-through copy in HBM.
+      if (ok) {
         const int pe = sp + (cnt - 1 - rank);
-        int4* slot = reinterpret_cast<int4*>(pool.base + stack.off + (int64_t)pe * KC);
         int4* lslot = reinterpret_cast<int4*>(lds_stack + (pe & (LDS_STACK - 1)) * KC);
         row[0] = cand_id;
 #pragma unroll
-        for (int t = 0; t < KC; t += 4) {
-          const int4 v = make_int4(row[t], row[t + 1], row[t + 2], row[t + 3]);
-          slot[t / 4] = v;
-          lslot[t / 4] = v;
+        for (int t = 0; t < KC; t += 4)
+          lslot[t / 4] = make_int4(row[t], row[t + 1], row[t + 2], row[t + 3]);
+        if (rank > 0) {
+          int4* slot = reinterpret_cast<int4*>(pool.base + stack.off + (int64_t)pe * KC);
+#pragma unroll
+          for (int t = 0; t < KC; t += 4)
+            slot[t / 4] = make_int4(row[t], row[t + 1], row[t + 2], row[t + 3]);
         }
       }
-      sp += cnt - 1;
+      sp += cnt;
       if (sp - lds_lo > LDS_STACK)
         lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)
-      // first child continues from registers: lane j of group 0 takes row_f[j + 1]
-      const int f = __ffsll(am) - 1;
-      int nxt = 0;
-#pragma unroll
-      for (int t = 1; t < KC; t++) {
-        const int v = readlane_i32(row[t], f);
-        nxt = (lane == t - 1) ? v : nxt;
-      }
-      child_cand = nxt;
-      have_child = true;
     }
   }
   if (need_state) {  // state of the very last expansion (the plane's reported normal / centre)
