@@ -20,7 +20,8 @@ STATUS = {0: "BS_OK", -1: "BS_ERR_INVALID", -2: "BS_ERR_RANGE", -3: "BS_ERR_NOME
 EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "bs_destroy", "bs_last_error",
            "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_knn_normals_halo", "bs_region_grow", "bs_segment",
            "bs_planes_free", "bs_plane_colors", "bs_knn_normals_dev", "bs_region_grow_dev",
-           "bs_segment_dev", "bs_planes_fetch", "bs_shift_to_origin_dev", "bs_plane_colors_dev"]
+           "bs_segment_dev", "bs_planes_fetch", "bs_shift_to_origin_dev", "bs_plane_colors_dev",
+           "bs_selftest_center_div"]
 
 
 class Params(C.Structure):
@@ -86,5 +87,6 @@ def load():
     L.bs_planes_fetch.argtypes = [vp, C.POINTER(Planes)]
     L.bs_shift_to_origin_dev.argtypes = [vp, ip, C.c_int64, ip]
     L.bs_plane_colors_dev.argtypes = [vp, ip, C.c_int32, C.c_int64, vp]
+    L.bs_selftest_center_div.argtypes = [vp, ip, vp, ip, C.c_int64]
     _LIB = L
     return L

@@ -179,6 +179,14 @@ class Context:
         rgb = np.ascontiguousarray(plane_rgb, dtype=np.int32).reshape(-1, 3)
         self._check(self._L.bs_plane_colors_dev(self._h, rgb.ctypes.data, len(rgb), n, d_colors))
 
+    def selftest_center_div(self, c, n):
+        """Device evaluation of (int32)((uint64)(int64)c / n) through csrc/bs_centerdiv.h."""
+        c = np.ascontiguousarray(c, dtype=np.int32)
+        n = np.ascontiguousarray(n, dtype=np.uint32)
+        out = np.empty_like(c)
+        self._check(self._L.bs_selftest_center_div(self._h, c.ctypes.data, n.ctypes.data, out.ctypes.data, len(c)))
+        return out
+
     def planes_fetch(self):
         P = Planes()
         self._check(self._L.bs_planes_fetch(self._h, C.byref(P)))

@@ -43,6 +43,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "bs_centerdiv.h"
 #include "bs_common.h"
 
 namespace bs {
@@ -399,6 +400,35 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   double cnx, cny, cnz, Sx, Sy, Sz;
   int ccx, ccy, ccz;
   uint32_t Cx, Cy, Cz;
+  // Deferred part of an expansion: the accepted points' normals and coordinates
+  // (lanes d_am of the d_* registers) enter the running sums in list order, then
+  // the plane's normal and centre follow.  It runs between the issue of the next
+  // gather and the first use of its data, i.e. under the memory latency.
+  unsigned long long d_am = 0;
+  double d_mx = 0, d_my = 0, d_mz = 0;
+  int d_px = 0, d_py = 0, d_pz = 0;
+  auto update_state = [&]() {
+    unsigned long long mm = d_am;
+    while (mm) {
+      const int l = __ffsll(mm) - 1;
+      mm &= mm - 1;
+      Sx += readlane_f64(d_mx, l);
+      Sy += readlane_f64(d_my, l);
+      Sz += readlane_f64(d_mz, l);
+      Cx += (uint32_t)readlane_i32(d_px, l);
+      Cy += (uint32_t)readlane_i32(d_py, l);
+      Cz += (uint32_t)readlane_i32(d_pz, l);
+    }
+    const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+    cnx = Sx / nrm;
+    cny = Sy / nrm;
+    cnz = Sz / nrm;
+    const CenterDiv cd = center_div_prepare((uint32_t)ln);  // int /= size_t (quirk Q3), see bs_centerdiv.h
+    ccx = center_div((int32_t)Cx, cd);
+    ccy = center_div((int32_t)Cy, cd);
+    ccz = center_div((int32_t)Cz, cd);
+    need_state = false;
+  };
   const bool have_mem = slab_ensure(pool, list, 0, 2048, lane) && slab_ensure(pool, stack, 0, 256 * (int64_t)KC, lane) &&
                         slab_ensure(pool, log, 0, 2048, lane);
   // A plane that loses a point to a sequentially earlier plane is invalid, but the
@@ -491,17 +521,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       // three 64-bit integer divisions) is evaluated HERE, between the issue of the
       // gather loads above and their first use below: ~500 cycles of arithmetic
       // that hide behind the memory latency instead of preceding it.
-      if (need_state) {
-        const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
-        cnx = Sx / nrm;
-        cny = Sy / nrm;
-        cnz = Sz / nrm;
-        const uint64_t dn = (uint64_t)ln;
-        ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);  // int /= size_t (quirk Q3)
-        ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
-        ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
-        need_state = false;
-      }
+      if (need_state)
+        update_state();
       bool geo = false;
       if (valid && act && tg != seed) {  // tg == seed: already labelled by this plane
         const int dx = (int)((uint32_t)px - (uint32_t)ccx);
@@ -603,19 +624,17 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       const int rank = __popcll(am & ((1ull << lane) - 1ull));
       if (ok)
         pool.base[list.off + ln + rank] = cand_id;
-      unsigned long long mm = am;
-      while (mm) {
-        const int l = __ffsll(mm) - 1;
-        mm &= mm - 1;
-        Sx += readlane_f64(mx, l);
-        Sy += readlane_f64(my, l);
-        Sz += readlane_f64(mz, l);
-        Cx += (uint32_t)readlane_i32(px, l);
-        Cy += (uint32_t)readlane_i32(py, l);
-        Cz += (uint32_t)readlane_i32(pz, l);
-      }
+      // the running sums (:231-248) and the plane state (:249-250) are evaluated
+      // after the next gather has been issued: keep what they need
+      d_am = am;
+      d_mx = mx;
+      d_my = my;
+      d_mz = mz;
+      d_px = px;
+      d_py = py;
+      d_pz = pz;
       ln += cnt;
-      need_state = true;  // :249-250 evaluated after the next gather has been issued
+      need_state = true;
       // the children go on the LIFO (reversed) with their rows; id in slot 0.  The
       // first child (top entry) is consumed by the very next call and therefore
       // never needs its write-through copy in HBM.
@@ -638,17 +657,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)
     }
   }
-  if (need_state) {  // state of the very last expansion (the plane's reported normal / centre)
-    const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
-    cnx = Sx / nrm;
-    cny = Sy / nrm;
-    cnz = Sz / nrm;
-    const uint64_t dn = (uint64_t)ln;
-    ccx = (int32_t)((uint64_t)(int64_t)(int32_t)Cx / dn);
-    ccy = (int32_t)((uint64_t)(int64_t)(int32_t)Cy / dn);
-    ccz = (int32_t)((uint64_t)(int64_t)(int32_t)Cz / dn);
-    need_state = false;
-  }
+  if (need_state)  // state of the very last expansion (the plane's reported normal / centre)
+    update_state();
   // Settle the claims of the last call on EVERY exit path (normal end, failed
   // depth 0, pool exhaustion, kill): a plane that took a point from a later
   // plane must mark that plane invalid even if it does not survive itself --

@@ -4,6 +4,7 @@
 // seg_plane::set_plane_color (/root/reference/tmc3/my_function.cpp:260-275).
 #include <climits>
 
+#include "bs_centerdiv.h"
 #include "bs_common.h"
 
 namespace bs {
@@ -112,6 +113,42 @@ extern "C" int bs_plane_colors_dev(bs_ctx* ctx, const int32_t* plane_rgb, int32_
     color_scatter_kernel<<<dim3(n_planes, 16), 256, 0, st>>>(ctx->rg_planes.as<PlaneRec>(), ctx->rg_list.as<int32_t>(),
                                                           d_rgb, n, d_colors);
   }
+  BS_HIP(ctx, hipStreamSynchronize(st));
+  BS_HIP(ctx, hipGetLastError());
+  return BS_OK;
+}
+
+namespace {
+__global__ void center_div_selftest_kernel(const int32_t* __restrict__ c, const uint32_t* __restrict__ n,
+                                           int32_t* __restrict__ out, int64_t count)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count)
+    return;
+  const bs::CenterDiv d = bs::center_div_prepare(n[i]);
+  out[i] = bs::center_div(c[i], d);
+}
+}  // namespace
+
+extern "C" int bs_selftest_center_div(bs_ctx* ctx, const int32_t* c, const uint32_t* n, int32_t* out, int64_t count)
+{
+  if (!ctx)
+    return BS_ERR_INVALID;
+  if (!c || !n || !out || count <= 0 || count > (1ll << 30))
+    return fail(ctx, BS_ERR_INVALID, "null pointer or bad count");
+  for (int64_t i = 0; i < count; i++)
+    if (n[i] == 0 || n[i] >= 0x80000000u)
+      return fail(ctx, BS_ERR_RANGE, "divisor outside 1 .. 2^31-1");
+  BS_HIP(ctx, hipSetDevice(ctx->device));
+  BS_HIP(ctx, ctx->misc.reserve((size_t)count * 12 + 256));
+  hipStream_t st = ctx->stream;
+  int32_t* d_c = ctx->misc.as<int32_t>() + 64;
+  uint32_t* d_n = reinterpret_cast<uint32_t*>(d_c + count);
+  int32_t* d_o = d_c + 2 * count;
+  BS_HIP(ctx, hipMemcpyAsync(d_c, c, sizeof(int32_t) * count, hipMemcpyHostToDevice, st));
+  BS_HIP(ctx, hipMemcpyAsync(d_n, n, sizeof(uint32_t) * count, hipMemcpyHostToDevice, st));
+  center_div_selftest_kernel<<<(int)((count + 255) / 256), 256, 0, st>>>(d_c, d_n, d_o, count);
+  BS_HIP(ctx, hipMemcpyAsync(out, d_o, sizeof(int32_t) * count, hipMemcpyDeviceToHost, st));
   BS_HIP(ctx, hipStreamSynchronize(st));
   BS_HIP(ctx, hipGetLastError());
   return BS_OK;

@@ -181,6 +181,13 @@ int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params
 int bs_shift_to_origin_dev(bs_ctx* ctx, int32_t* d_xyz, int64_t n, int32_t* min_out);
 int bs_plane_colors_dev(bs_ctx* ctx, const int32_t* plane_rgb, int32_t n_planes, int64_t n, uint16_t* d_colors);
 
+/* Self-test of the grower's plane-centre division (csrc/bs_centerdiv.h) ON THE
+ * DEVICE: out[i] = (int32_t)((uint64_t)(int64_t)c[i] / n[i]), the expression of
+ * my_function.cpp:249-250, for count host-side pairs (1 <= n[i] < 2^31).  The
+ * device version rests on the hardware reciprocal seed, which no host test can
+ * exercise; tests/test_gpu_parity.py checks millions of pairs through this. */
+int bs_selftest_center_div(bs_ctx* ctx, const int32_t* c, const uint32_t* n, int32_t* out, int64_t count);
+
 /* Copy the plane records of the last region-grow on this context to the host. */
 int bs_planes_fetch(bs_ctx* ctx, bs_planes* planes);
 
