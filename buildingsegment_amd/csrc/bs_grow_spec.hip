@@ -703,8 +703,12 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   }
 }
 
+// The per-plane list kernels run one BLOCK of VT threads per plane: a 100 k-point
+// list walked by a single wave is 1700 dependent gathers per lane (0.7 ms).
+constexpr int VT = 1024;
+
 // every accepted point must still carry this plane's claim
-__global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
+__global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
                                                        int4* rec, int quads, const int32_t* __restrict__ dead, int64_t n)
 {
   const int w = blockIdx.x;
@@ -713,9 +717,9 @@ __global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand,
   const PlaneOut o = out[w];
   // lost a point after it had finished, or an impossible list (each point at most once + the seed)
   bool bad = dead[o.seed] != 0 || o.list_n > n + 1;
-  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64)
+  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT)
     bad = bad || *rec_tag(rec, quads, pool[o.list_off + t]) != o.seed;
-  const unsigned long long b = __ballot(bad);
+  const int b = __syncthreads_or(bad);  // (also orders the reads of out[w] above before the write below)
   if (threadIdx.x == 0) {
     if (b)
       out[w].status = ST_STOLEN;
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(64) void validate1_kernel(PlaneOut* out, int ncand,
 // A finished plane enters the owner structure: its seed stops being an orphan
 // maker and its kept points get the plane as base owner.  drop undoes it.
 // (PlaneOut.pad carries the host's per-plane command: 1 = insert, 2 = drop.)
-__global__ __launch_bounds__(64) void plane_apply_kernel(const PlaneOut* __restrict__ arr, int cnt,
+__global__ __launch_bounds__(VT) void plane_apply_kernel(const PlaneOut* __restrict__ arr, int cnt,
                                                          const int32_t* __restrict__ pool, int32_t* base,
                                                          uint8_t* ps, uint8_t* dirty)
 {
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(64) void plane_apply_kernel(const PlaneOut* __restr
   }
   if (!o.keep)
     return;
-  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64) {
+  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT) {
     const int32_t p = pool[o.list_off + t];
     if (ins)
       atomicMin(&base[p], o.seed);
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(64) void plane_apply_kernel(const PlaneOut* __restr
   }
 }
 
-__global__ __launch_bounds__(64) void validate2_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
+__global__ __launch_bounds__(VT) void validate2_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
                                                        const int32_t* __restrict__ omega,
                                                        const int32_t* __restrict__ neigh, int K)
 {
@@ -768,11 +772,11 @@ __global__ __launch_bounds__(64) void validate2_kernel(PlaneOut* out, int ncand,
     bad = omega[s] < s;  // (1) the seed is still free at its time ...
   if (threadIdx.x >= 1 && threadIdx.x < K)
     bad = omega[neigh[(int64_t)s * K + threadIdx.x]] < s;  // ... and so are its K-1 neighbours
-  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += 64)  // (2) accepted points were free
+  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT)  // (2) accepted points were free
     bad = bad || omega[pool[o.list_off + t]] < s;
-  for (int64_t t = threadIdx.x; t < o.log_n; t += 64)  // (3) assumed-taken points are taken
+  for (int64_t t = threadIdx.x; t < o.log_n; t += VT)  // (3) assumed-taken points are taken
     bad = bad || !(omega[pool[o.log_off + t]] < s);
-  const unsigned long long b = __ballot(bad);
+  const int b = __syncthreads_or(bad);
   if (threadIdx.x == 0)
     out[w].consistent = b ? 0 : 1;
 }
@@ -1048,16 +1052,16 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
-      validate1_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n);
+      validate1_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n);
       // insert the finished planes and let the owners settle
-      plane_apply_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
+      plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
       rc = propagate();
       if (rc != BS_OK)
         return rc;
-      validate2_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, omega, d_neigh, K);
+      validate2_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, omega, d_neigh, K);
     }
     if (npend)
-      validate2_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, omega, d_neigh, K);
+      validate2_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, omega, d_neigh, K);
     int32_t inf = INF;
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 2, &inf, sizeof inf, hipMemcpyHostToDevice, st));
     cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, d_misc + 2);
@@ -1179,11 +1183,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     if (dropped) {
       if (ncand) {
         BS_HIP(ctx, hipMemcpyAsync(d_out, h_out.data(), sizeof(PlaneOut) * ncand, hipMemcpyHostToDevice, st));
-        plane_apply_kernel<<<ncand, 64, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
+        plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
       }
       if (npend) {
         BS_HIP(ctx, hipMemcpyAsync(d_pend, h_pend.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
-        plane_apply_kernel<<<npend, 64, 0, st>>>(d_pend, npend, pstore, base, ps, dcur);
+        plane_apply_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, base, ps, dcur);
       }
       rc = propagate();
       if (rc != BS_OK)
