@@ -179,6 +179,25 @@ class Context:
         rgb = np.ascontiguousarray(plane_rgb, dtype=np.int32).reshape(-1, 3)
         self._check(self._L.bs_plane_colors_dev(self._h, rgb.ctypes.data, len(rgb), n, d_colors))
 
+    def grid_picture(self, xyz, extent=None, bin=100, bin_height=1000):
+        """buildingSeg::compute_gird_picture (TMC3.cpp:123-174) of a cloud already shifted to
+        its bounding-box origin.  Returns (image [height][width][3] f64, ground_th)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        ext = np.ascontiguousarray(xyz.max(0) if extent is None else extent, dtype=np.int32)
+        w, h = grid_dims(ext, bin)
+        img = np.empty((h, w, 3), dtype=np.float64)
+        th = C.c_double(0)
+        self._check(self._L.bs_grid_picture(self._h, xyz.ctypes.data, len(xyz), ext.ctypes.data, bin, bin_height,
+                                            img.ctypes.data, C.byref(th)))
+        return img, th.value
+
+    def grid_picture_dev(self, d_xyz, n, extent, d_image, bin=100, bin_height=1000):
+        """Device-resident variant: d_xyz / d_image are device pointers (ints)."""
+        ext = np.ascontiguousarray(extent, dtype=np.int32)
+        th = C.c_double(0)
+        self._check(self._L.bs_grid_picture_dev(self._h, d_xyz, n, ext.ctypes.data, bin, bin_height, d_image, C.byref(th)))
+        return th.value
+
     def selftest_center_div(self, c, n):
         """Device evaluation of (int32)((uint64)(int64)c / n) through csrc/bs_centerdiv.h."""
         c = np.ascontiguousarray(c, dtype=np.int32)
@@ -193,6 +212,51 @@ class Context:
         planes = _planes_to_list(P)
         self._L.bs_planes_free(C.byref(P))
         return planes
+
+
+def grid_dims(extent, bin=100):
+    """(width, height) of the 2-D raster (TMC3.cpp:75-76)."""
+    ext = np.ascontiguousarray(extent, dtype=np.int32)
+    w, h = C.c_int32(0), C.c_int32(0)
+    rc = _lib.load().bs_grid_dims(ext.ctypes.data, bin, C.byref(w), C.byref(h))
+    if rc != 0:
+        raise ValueError("bs_grid_dims: invalid extent / bin")
+    return w.value, h.value
+
+
+def save_image(image, prefix):
+    """buildingSeg::save_image (TMC3.cpp:81-117): three 8-bit RGB PNGs -- mean height in the
+    red channel, density in the green channel, and the (never written, all zero) third
+    channel in green.  Each channel is scaled by its maximum and truncated to uint8.
+    The reference's file names are prefix + a Chinese caption; this port uses ASCII
+    suffixes (height / density / density_height).  Returns the three uint8 arrays."""
+    img = np.asarray(image, dtype=np.float64)
+    h, w, _ = img.shape
+    mx = [max(0.0, float(img[..., c].max())) for c in range(3)]  # `max` starts at 0 (TMC3.cpp:85)
+    outs = []
+    for c, slot, name in ((0, 0, "height"), (1, 1, "density"), (2, 1, "density_height")):
+        out = np.zeros((h, w, 3), dtype=np.uint8)
+        if mx[c] != 0:
+            out[..., slot] = (255.0 * (1.0 * img[..., c] / mx[c])).astype(np.uint8)
+        write_png(prefix + name + ".png", out)
+        outs.append(out)
+    return outs
+
+
+def write_png(path, rgb):
+    """Minimal 8-bit RGB PNG writer (zlib from the standard library)."""
+    import struct
+    import zlib
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
 _DEFAULT_CTX = None

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbuildingsegment_hip.so")
-SOURCES = ["bs_capi.hip", "bs_grid.hip", "bs_knn.hip", "bs_grow.hip", "bs_grow_spec.hip", "bs_prepost.hip"]
+SOURCES = ["bs_capi.hip", "bs_grid.hip", "bs_knn.hip", "bs_grow.hip", "bs_grow_spec.hip", "bs_prepost.hip", "bs_raster.hip"]
 HEADERS = ["bs_common.h", "bs_normal.h", "bs_centerdiv.h", "../../include/bs_api.h", "../../include/bs_detmath.h"]
 # -ffp-contract=off: no FMA fusion anywhere -- host and device must round identically.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",

@@ -6,6 +6,10 @@
 //   class seg_plane                       /root/reference/tmc3/my_function.h:89-123
 //     get_planes()                        /root/reference/tmc3/my_function.cpp:180-217
 //     set_plane_color(planes)             /root/reference/tmc3/my_function.cpp:260-275
+//   class buildingSeg (2-D raster branch) /root/reference/tmc3/TMC3.cpp:50-200
+//     buildingSeg(cloud)                  TMC3.cpp:55-79  (bbox, shift, image dims)
+//     compute_gird_picture()              TMC3.cpp:123-174 (+ groundTH, :183-199)
+//     save_image(prefix), pixel(x,y,c)    TMC3.cpp:81-121
 //
 // Generic over the cloud / vector types so that it works both with the
 // reference's pcc::PCCPointSet3 + pcc::Vec3<T> (drop-in: define
@@ -18,8 +22,11 @@
 // my_function.h:81 is intentionally not reproduced.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <limits>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -151,9 +158,151 @@ private:
   int th_pointCount = 400;  // my_function.h:118
 };
 
+// ---- 2-D raster branch ------------------------------------------------------
+// 8-bit RGB PNG with stored (uncompressed) deflate blocks: enough for a debug
+// image dump, no dependency.  (The reference uses stb_image_write.)
+inline bool write_png_rgb8(const std::string& path, int w, int h, const std::vector<uint8_t>& rgb)
+{
+  auto crc32 = [](const uint8_t* d, size_t n, uint32_t c) {
+    c = ~c;
+    for (size_t i = 0; i < n; i++) {
+      c ^= d[i];
+      for (int k = 0; k < 8; k++)
+        c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    }
+    return ~c;
+  };
+  auto be32 = [](std::vector<uint8_t>& v, uint32_t x) {
+    for (int s = 24; s >= 0; s -= 8)
+      v.push_back((uint8_t)(x >> s));
+  };
+  std::vector<uint8_t> raw;  // filter byte 0 + row
+  raw.reserve((size_t)h * (3 * (size_t)w + 1));
+  for (int y = 0; y < h; y++) {
+    raw.push_back(0);
+    raw.insert(raw.end(), rgb.begin() + (size_t)y * 3 * w, rgb.begin() + (size_t)(y + 1) * 3 * w);
+  }
+  std::vector<uint8_t> z = {0x78, 0x01};
+  uint32_t a = 1, b = 0;
+  for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+    const size_t len = std::min<size_t>(65535, raw.size() - pos);
+    const bool last = pos + len >= raw.size();
+    z.push_back(last ? 1 : 0);
+    z.push_back((uint8_t)(len & 255));
+    z.push_back((uint8_t)(len >> 8));
+    z.push_back((uint8_t)(~len & 255));
+    z.push_back((uint8_t)((~len >> 8) & 255));
+    for (size_t i = 0; i < len; i++) {
+      a = (a + raw[pos + i]) % 65521u;
+      b = (b + a) % 65521u;
+    }
+    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + len);
+    pos += len;
+    if (last)
+      break;
+  }
+  be32(z, (b << 16) | a);
+  std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  auto chunk = [&](const char* tag, const std::vector<uint8_t>& data) {
+    be32(out, (uint32_t)data.size());
+    std::vector<uint8_t> td(tag, tag + 4);
+    td.insert(td.end(), data.begin(), data.end());
+    out.insert(out.end(), td.begin(), td.end());
+    be32(out, crc32(td.data(), td.size(), 0));
+  };
+  std::vector<uint8_t> ihdr;
+  be32(ihdr, (uint32_t)w);
+  be32(ihdr, (uint32_t)h);
+  const uint8_t tail[5] = {8, 2, 0, 0, 0};
+  ihdr.insert(ihdr.end(), tail, tail + 5);
+  chunk("IHDR", ihdr);
+  chunk("IDAT", z);
+  chunk("IEND", {});
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f)
+    return false;
+  const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+  fclose(f);
+  return ok;
+}
+
+// The reference's buildingSeg (TMC3.cpp:50-200) on the C ABI.  As in the
+// reference, the constructor keeps its own copy of the cloud, shifts BOTH the
+// copy and the caller's cloud to the bounding-box origin and sizes the image.
+template <class Cloud>
+class buildingSeg_t {
+public:
+  Cloud pointcloud;
+
+  explicit buildingSeg_t(Cloud& cloud) : pointcloud(cloud)
+  {
+    const size_t n = cloud.getPointCount();
+    for (int k = 0; k < 3; k++) {
+      box_min[k] = std::numeric_limits<int32_t>::max();
+      box_max[k] = std::numeric_limits<int32_t>::lowest();
+    }
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        const int32_t v = cloud[i][k];
+        if (v > box_max[k])
+          box_max[k] = v;
+        if (v < box_min[k])
+          box_min[k] = v;
+      }
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        pointcloud[i][k] -= box_min[k];
+        cloud[i][k] = pointcloud[i][k];
+      }
+    int32_t ext[3] = {box_max[0] - box_min[0], box_max[1] - box_min[1], box_max[2] - box_min[2]};
+    if (n == 0 || bs_grid_dims(ext, bin, &width, &height) != BS_OK)
+      throw std::runtime_error("buildingSeg: empty cloud");
+    image.assign((size_t)width * height * channels, 0.0);
+  }
+
+  double& pixel(int x, int y, int channel) { return image[((size_t)y * width + x) * channels + channel]; }
+
+  void compute_gird_picture()
+  {
+    const int32_t ext[3] = {box_max[0] - box_min[0], box_max[1] - box_min[1], box_max[2] - box_min[2]};
+    legacy_check(bs_grid_picture(legacy_ctx(), reinterpret_cast<const int32_t*>(&pointcloud[0]),
+                                 (int64_t)pointcloud.getPointCount(), ext, bin, bin_height, image.data(), &ground_th));
+  }
+
+  // three PNGs: mean height (red), density (green), third channel (green; never written by
+  // compute_gird_picture, i.e. black).  ASCII suffixes replace the reference's Chinese captions.
+  void save_image(const std::string& savePath)
+  {
+    double mx[3] = {0, 0, 0};
+    for (int i = 0; i < width; i++)
+      for (int j = 0; j < height; j++)
+        for (int c = 0; c < channels; c++)
+          if (mx[c] < pixel(i, j, c))
+            mx[c] = pixel(i, j, c);
+    const char* names[3] = {"height.png", "density.png", "density_height.png"};
+    const int slot[3] = {0, 1, 1};
+    for (int c = 0; c < 3; c++) {
+      std::vector<uint8_t> img((size_t)width * height * channels, 0);
+      if (mx[c] != 0)
+        for (int i = 0; i < width; i++)
+          for (int j = 0; j < height; j++)
+            img[((size_t)i + (size_t)j * width) * channels + slot[c]] = (uint8_t)(255.0 * (1.0 * pixel(i, j, c) / mx[c]));
+      if (!write_png_rgb8(savePath + names[c], width, height, img))
+        throw std::runtime_error("save_image: cannot write " + savePath + names[c]);
+    }
+  }
+
+  int32_t box_min[3], box_max[3];
+  int32_t bin = 100, bin_height = 1000;  // TMC3.cpp:179
+  int32_t width = 0, height = 0, channels = 3;
+  double ground_th = 0;
+  std::vector<double> image;
+};
+
 }  // namespace bs
 
 #ifdef BS_LEGACY_PCC
+using buildingSeg = bs::buildingSeg_t<pcc::PCCPointSet3>;
 // Drop-in names for the reference tree (include PCCPointSet.h first).
 using plane = bs::plane_t<pcc::Vec3<double>, pcc::Vec3<int>>;
 using seg_plane = bs::seg_plane_t<pcc::PCCPointSet3, pcc::Vec3<double>, pcc::Vec3<int>, pcc::Vec3<pcc::attr_t>>;

@@ -26,7 +26,7 @@ static std::string after_equals(const char* arg)  // Split(path, "=")[1], my_fun
 int main(int argc, char* argv[])
 {
   if (argc < 3) {
-    fprintf(stderr, "usage: %s <x>=<in.ply> <y>=<out.ply>\n", argv[0]);
+    fprintf(stderr, "usage: %s <x>=<in.ply> <y>=<out.ply> [--raster=<png prefix>]\n", argv[0]);
     return 2;
   }
   const std::string in = after_equals(argv[1]), out = after_equals(argv[2]);
@@ -42,15 +42,12 @@ int main(int argc, char* argv[])
     return bs::ply::write(cloud, 1.0, z, out, ascii, &err) ? 0 : 1;
   }
   const size_t n = cloud.getPointCount();
-  int mn[3] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::max(), std::numeric_limits<int>::max()};
-  for (size_t i = 0; i < n; i++)
-    for (int k = 0; k < 3; k++)
-      if (cloud[i][k] < mn[k])
-        mn[k] = cloud[i][k];
-  for (size_t i = 0; i < n; i++)
-    for (int k = 0; k < 3; k++)
-      cloud[i][k] -= mn[k];
+  std::string raster_prefix;  // --raster=<prefix>: the 2-D branch the reference's main keeps commented out (TMC3.cpp:223-225)
+  for (int a = 3; a < argc; a++)
+    if (std::string(argv[a]).rfind("--raster=", 0) == 0)
+      raster_prefix = after_equals(argv[a]);
   try {
+    bs::buildingSeg_t<Cloud> seg(cloud);  // bounding box + shift to the origin (TMC3.cpp:209)
     std::vector<VecD> normal;
     std::vector<std::vector<int>> neigh;
     bs::get_Normal_and_K_neighbor<15>(cloud, normal, neigh);
@@ -62,6 +59,11 @@ int main(int argc, char* argv[])
     srand(1);
     h.set_plane_color(planes);
     fprintf(stderr, "tmc3: %zu points, %zu planes\n", n, planes.size());
+    if (!raster_prefix.empty()) {
+      seg.compute_gird_picture();
+      seg.save_image(raster_prefix);
+      fprintf(stderr, "tmc3: raster %d x %d, ground threshold %.0f mm\n", seg.width, seg.height, seg.ground_th);
+    }
   } catch (const std::exception& e) {
     fprintf(stderr, "tmc3: %s\n", e.what());
     return 1;

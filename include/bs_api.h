@@ -181,6 +181,31 @@ int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params
 int bs_shift_to_origin_dev(bs_ctx* ctx, int32_t* d_xyz, int64_t n, int32_t* min_out);
 int bs_plane_colors_dev(bs_ctx* ctx, const int32_t* plane_rgb, int32_t n_planes, int64_t n, uint16_t* d_colors);
 
+/* 2-D density / height raster: the reference's (currently commented-out) 2-D
+ * branch, SURVEY.md 8f-4.  Replaces buildingSeg::groundTH (TMC3.cpp:183-199) and
+ * buildingSeg::compute_gird_picture (TMC3.cpp:123-174) for a cloud that has
+ * already been shifted to its bounding-box origin (bs_shift_to_origin_dev, i.e.
+ * the buildingSeg constructor, TMC3.cpp:55-73).
+ *
+ *   extent[3]  = box.max - box.min of the unshifted cloud (= max of the shifted one)
+ *   bin        = pixel edge in mm (reference: 100), bin_height = height-histogram
+ *                bin in mm (reference: 1000)
+ *   bs_grid_dims: width = extent[0]/bin + 2, height = extent[1]/bin + 2 (TMC3.cpp:75-76)
+ *   image      = [height][width][3] f64, caller-allocated, pixel(x,y,c) at
+ *                (y*width + x)*3 + c as in TMC3.cpp:119-121:
+ *                  c=0 mean height of the splatted points, c=1 log(density+1) (+20
+ *                  where non-zero), c=2 zero (the reference never writes it)
+ *   ground_th  (host, nullable) receives groundTH()
+ * Bit-identical to the reference's sequential f64 accumulation in channel 0 and in
+ * the density sums; the logarithm is bs_det_log of include/bs_detmath.h (within
+ * 1 ulp of the platform libm the reference calls).  BS_ERR_RANGE if a coordinate
+ * lies outside [0, extent].  Synchronises. */
+int bs_grid_dims(const int32_t* extent, int32_t bin, int32_t* width, int32_t* height);
+int bs_grid_picture(bs_ctx* ctx, const int32_t* xyz, int64_t n, const int32_t* extent, int32_t bin,
+                    int32_t bin_height, double* image, double* ground_th);
+int bs_grid_picture_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const int32_t* extent, int32_t bin,
+                        int32_t bin_height, double* d_image, double* ground_th);
+
 /* Self-test of the grower's plane-centre division (csrc/bs_centerdiv.h) ON THE
  * DEVICE: out[i] = (int32_t)((uint64_t)(int64_t)c[i] / n[i]), the expression of
  * my_function.cpp:249-250, for count host-side pairs (1 <= n[i] < 2^31).  The

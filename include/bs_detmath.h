@@ -156,4 +156,52 @@ BS_HD double bs_det_cos(double x)
   }
 }
 
+/*
+ * bs_det_log: natural logarithm for the density channel of the 2-D raster
+ * (reference call site: std::log in buildingSeg::compute_gird_picture,
+ * /root/reference/tmc3/TMC3.cpp:165).  Same reasoning as above: libm's log is
+ * platform-defined in its last bit, so one scheme is fixed for oracle and device.
+ * Classic fdlibm-style evaluation: x = 2^k * (1 + f) with sqrt(2)/2 < 1+f < sqrt(2),
+ * s = f / (2 + f), log(1+f) = f - f*f/2 + s*(f*f/2 + R(s*s)), R a degree-7 minimax
+ * polynomial in s*s; log(x) = k*ln2_hi - ((hfsq - (s*(hfsq+R) + k*ln2_lo)) - f).
+ * Domain: finite normal x >= 2^-1022 (the raster only calls it with x >= 1).
+ * Within 1 ulp of glibc's log (tests/test_detmath.py).
+ */
+BS_HD double bs_det_log(double x)
+{
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  uint64_t u;
+  memcpy(&u, &x, sizeof u);
+  int32_t hx = (int32_t)(u >> 32);
+  int32_t k = (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  const int32_t i0 = (hx + 0x95f64) & 0x100000; /* 1+f >= sqrt(2): halve it, k += 1 */
+  u = ((uint64_t)(uint32_t)(hx | (i0 ^ 0x3ff00000)) << 32) | (u & 0xFFFFFFFFull);
+  memcpy(&x, &u, sizeof u);
+  k += i0 >> 20;
+  const double f = x - 1.0;
+  const double dk = (double)k;
+  if ((0x000fffff & (2 + hx)) < 3) { /* |f| < 2^-20 */
+    if (f == 0.0)
+      return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+    const double R = f * f * (0.5 - 0.33333333333333333 * f);
+    return k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+  }
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  const int32_t i = (hx - 0x6147a) | (0x6b851 - hx);
+  if (i > 0) {
+    const double hfsq = 0.5 * f * f;
+    return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  }
+  return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
 #endif /* BS_DETMATH_H */

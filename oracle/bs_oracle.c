@@ -17,6 +17,11 @@
 double bso_det_acos(double x) { return bs_det_acos(x); }
 double bso_det_cos(double x) { return bs_det_cos(x); }
 
+double bso_det_log(double x)
+{
+  return bs_det_log(x);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Stage 2 arithmetic: covariance by cumulants + FastEigen3x3 + orientation  */
 /* ------------------------------------------------------------------------ */
@@ -786,4 +791,75 @@ void bso_planes_free(bso_planes* p)
   free(p->offset);
   free(p->point_idx);
   memset(p, 0, sizeof *p);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 2-D raster (TMC3.cpp:75-76, :123-174, :183-199)                            */
+/* ------------------------------------------------------------------------- */
+int bso_grid_dims(const int32_t extent[3], int32_t bin, int32_t* width, int32_t* height)
+{
+  if (!extent || bin <= 0 || extent[0] < 0 || extent[1] < 0)
+    return -1;
+  *width = extent[0] / bin + 2;  /* TMC3.cpp:75 */
+  *height = extent[1] / bin + 2; /* TMC3.cpp:76 */
+  return 0;
+}
+
+int bso_grid_picture(const int32_t* xyz, int64_t n, const int32_t extent[3], int32_t bin, int32_t bin_height,
+                           int libm_log, double* image, double* ground_th)
+{
+  int32_t width, height;
+  if (!xyz || n <= 0 || !image || bin_height <= 0 || bso_grid_dims(extent, bin, &width, &height) != 0 ||
+      extent[2] < 0)
+    return -1;
+  /* groundTH (TMC3.cpp:183-199) */
+  const int64_t nb = (int64_t)extent[2] / bin_height + 1;
+  int* hist = (int*)calloc((size_t)nb, sizeof(int));
+  if (!hist)
+    return -1;
+  const int TH = (int)(n / 2);
+  for (int64_t i = 0; i < n; i++)
+    hist[xyz[3 * i + 2] / bin_height]++;
+  int total = 0;
+  int64_t b;
+  for (b = 0; b < nb; b++) {
+    total += hist[b];
+    if (total > TH)
+      break;
+  }
+  free(hist);
+  const double th = (double)(int)(b * bin_height);
+  if (ground_th)
+    *ground_th = th;
+  /* compute_gird_picture (TMC3.cpp:123-174) */
+  const int64_t npix = (int64_t)width * height;
+  for (int64_t q = 0; q < npix * 3; q++)
+    image[q] = 0.0;
+  for (int64_t i = 0; i < n; i++) {
+    const int32_t px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+    const int x = px / bin, y = py / bin;
+    for (int xi = 0; xi < 2; xi++)
+      for (int yi = 0; yi < 2; yi++) {
+        if ((double)pz < th)
+          continue;
+        const double w = 1.0 * px / bin - x;
+        const double h = 1.0 * py / bin - y;
+        const double s = ((xi == 1) ? w : (1 - w)) * ((yi == 1) ? h : (1 - h));
+        double* p = image + ((int64_t)(y + yi) * width + (x + xi)) * 3;
+        p[1] += s;
+        p[0] += s * pz;
+      }
+  }
+  for (int64_t q = 0; q < npix; q++) {
+    double* p = image + q * 3;
+    if (p[1] != 0)
+      p[0] = p[0] / p[1];
+  }
+  for (int64_t q = 0; q < npix; q++) {
+    double* p = image + q * 3;
+    p[1] = libm_log ? log(p[1] + 1) : bs_det_log(p[1] + 1);
+    if (p[1] != 0)
+      p[1] += 20;
+  }
+  return 0;
 }

@@ -67,6 +67,25 @@ void bso_planes_free(bso_planes* planes);
 
 double bso_det_acos(double x);
 double bso_det_cos(double x);
+double bso_det_log(double x);
+
+/*
+ * 2-D density / height raster of the reference's (currently disabled) 2-D branch:
+ * buildingSeg::buildingSeg dims (TMC3.cpp:75-76), groundTH (:183-199) and
+ * compute_gird_picture (:123-174).  xyz is the cloud AFTER the constructor's
+ * bounding-box shift (all coordinates >= 0); extent = box.max - box.min.
+ *   width = extent[0]/bin + 2, height = extent[1]/bin + 2,
+ *   image[(y*width + x)*3 + c]: c=0 mean height above nothing (sum(s*z)/sum(s)),
+ *   c=1 log(sum(s)+1) (+20 where non-zero), c=2 untouched (0).
+ * Every point at or above the ground threshold (the 1000-mm height bin in which
+ * the running count first exceeds n/2) is splatted bilinearly into 4 pixels, in
+ * point order -- the f64 sums depend on that order.
+ * libm_log != 0: std::log as the reference; 0: bs_det_log (what the device uses).
+ * Returns 0, or -1 on invalid arguments.
+ */
+int bso_grid_dims(const int32_t extent[3], int32_t bin, int32_t* width, int32_t* height);
+int bso_grid_picture(const int32_t* xyz, int64_t n, const int32_t extent[3], int32_t bin, int32_t bin_height,
+                           int libm_log, double* image, double* ground_th);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,11 @@ def lib():
         L.bso_det_acos.restype = C.c_double
         L.bso_det_cos.argtypes = [C.c_double]
         L.bso_det_cos.restype = C.c_double
+        L.bso_det_log.argtypes = [C.c_double]
+        L.bso_det_log.restype = C.c_double
+        L.bso_grid_dims.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.bso_grid_picture.argtypes = [ip, C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int, dp,
+                                       C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 
@@ -137,6 +142,35 @@ def det_cos(x):
     return lib().bso_det_cos(float(x))
 
 
+def det_log(x):
+    return lib().bso_det_log(float(x))
+
+
+def grid_dims(extent, bin=100):
+    """(width, height) of the 2-D raster (TMC3.cpp:75-76)."""
+    ext = (C.c_int32 * 3)(*[int(v) for v in extent])
+    w, h = C.c_int32(0), C.c_int32(0)
+    if lib().bso_grid_dims(ext, bin, C.byref(w), C.byref(h)) != 0:
+        raise ValueError("bso_grid_dims failed")
+    return w.value, h.value
+
+
+def grid_picture(xyz, extent=None, bin=100, bin_height=1000, libm_log=False):
+    """buildingSeg::compute_gird_picture on a cloud that is already shifted to the
+    origin.  Returns (image [height][width][3] f64, ground_th)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    if extent is None:
+        extent = xyz.max(0)
+    w, h = grid_dims(extent, bin)
+    ext = (C.c_int32 * 3)(*[int(v) for v in extent])
+    img = np.empty((h, w, 3), dtype=np.float64)
+    th = C.c_double(0)
+    rc = lib().bso_grid_picture(_ip(xyz), len(xyz), ext, bin, bin_height, 1 if libm_log else 0, _dp(img), C.byref(th))
+    if rc != 0:
+        raise ValueError(f"bso_grid_picture failed: {rc}")
+    return img, th.value
+
+
 # --------------------------------------------------------------------------
 # verbatim reference stage 3 (oracle/_ref/ref_stage3): build container only
 # --------------------------------------------------------------------------
@@ -184,3 +218,32 @@ def ref_region_grow(xyz, normals, neigh, timeout=3600):
               "center": np.array(ctr, np.int32).reshape(-1, 3), "offset": np.array(off, np.int64),
               "point_idx": np.concatenate(pidx).astype(np.int32) if pidx else np.zeros(0, np.int32)}
     return plane_idx, planes, colors
+
+
+def ref_raster_path():
+    p = os.path.join(_HERE, "_ref", "ref_raster")
+    return p if os.path.exists(p) else None
+
+
+def ref_grid_picture(xyz, png_prefix=None, timeout=3600):
+    """Run the reference's own buildingSeg (constructor shift, groundTH,
+    compute_gird_picture; TMC3.cpp:44-200) on an UNSHIFTED cloud.  Returns
+    dict(width, height, min, max, ground_th, image[height][width][3])."""
+    exe = ref_raster_path()
+    if exe is None:
+        raise FileNotFoundError("oracle/_ref/ref_raster not built (run `make -C oracle ref` where /root/reference exists)")
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    with tempfile.TemporaryDirectory() as td:
+        fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(np.int64(len(xyz)).tobytes())
+            f.write(xyz.tobytes())
+        cmd = [exe, fi, fo] + ([png_prefix] if png_prefix else [])
+        subprocess.run(cmd, check=True, timeout=timeout)
+        raw = open(fo, "rb").read()
+    w, h = np.frombuffer(raw, np.int32, 2, 0)
+    mn = np.frombuffer(raw, np.int32, 3, 8).copy()
+    mx = np.frombuffer(raw, np.int32, 3, 20).copy()
+    th = float(np.frombuffer(raw, np.float64, 1, 32)[0])
+    img = np.frombuffer(raw, np.float64, int(w) * int(h) * 3, 40).reshape(int(h), int(w), 3).copy()
+    return {"width": int(w), "height": int(h), "min": mn, "max": mx, "ground_th": th, "image": img}

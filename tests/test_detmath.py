@@ -22,3 +22,15 @@ def test_det_cos_within_2ulp(oracle):
     for xs in (a, b):
         got = np.array([oracle.det_cos(x) for x in xs])
         assert _ulp(got, np.cos(xs)).max() <= 2.0
+
+
+def test_det_log_within_1ulp(oracle):
+    """bs_det_log (density channel of the 2-D raster, TMC3.cpp:158) against libm."""
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([1 + rng.uniform(0, 10, 20000), 1 + rng.uniform(0, 1e6, 20000), 1 + np.logspace(-16, 3, 500),
+                         [1.0, 2.0, np.e, 1.5, 1 + 2.0 ** -30, 4.0, 1e300, 2.0 ** -1000]])
+    got = np.array([oracle.det_log(x) for x in xs])
+    ref = np.log(xs)
+    assert got[0] == got[0] and oracle.det_log(1.0) == 0.0
+    nz = ref != 0
+    assert _ulp(got[nz], ref[nz]).max() <= 1.0

@@ -12,7 +12,8 @@ import os
 import numpy as np
 import pytest
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+              if not os.path.basename(p).startswith("raster_"))  # stage-3 fixtures (the raster ones: test_*raster.py)
 
 
 def test_fixtures_present():
