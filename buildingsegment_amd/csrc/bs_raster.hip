@@ -23,18 +23,39 @@
 namespace bs {
 namespace {
 
-__global__ void zhist_kernel(const int32_t* __restrict__ xyz, int64_t n, int3 extent, int bin_height,
-                             int* __restrict__ hist, int* __restrict__ bad)
+// Height histogram.  A city block has a few dozen 1000-mm height bins: global atomics
+// on so few addresses serialise in L2 (10 M points: 18 ms), so every block counts in
+// LDS first and flushes its non-zero bins once (bins >= ZH_LDS go to HBM directly).
+constexpr int ZH_LDS = 4096;
+constexpr int ZH_PER_THREAD = 32;
+
+__global__ __launch_bounds__(256) void zhist_kernel(const int32_t* __restrict__ xyz, int64_t n, int3 extent,
+                                                    int bin_height, int* __restrict__ hist, int* __restrict__ bad)
 {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-  if (x < 0 || y < 0 || z < 0 || x > extent.x || y > extent.y || z > extent.z) {
-    *bad = 1;  // not the shifted cloud this extent belongs to: the splat would leave the image
-    return;
+  __shared__ int lh[ZH_LDS];
+  for (int t = threadIdx.x; t < ZH_LDS; t += blockDim.x)
+    lh[t] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * blockDim.x * ZH_PER_THREAD;
+  for (int r = 0; r < ZH_PER_THREAD; r++) {
+    const int64_t i = base + (int64_t)r * blockDim.x + threadIdx.x;
+    if (i >= n)
+      break;
+    const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (x < 0 || y < 0 || z < 0 || x > extent.x || y > extent.y || z > extent.z) {
+      *bad = 1;  // not the shifted cloud this extent belongs to: the splat would leave the image
+      continue;
+    }
+    const int b = z / bin_height;
+    if (b < ZH_LDS)
+      atomicAdd(&lh[b], 1);
+    else
+      atomicAdd(&hist[b], 1);
   }
-  atomicAdd(&hist[z / bin_height], 1);
+  __syncthreads();
+  for (int t = threadIdx.x; t < ZH_LDS; t += blockDim.x)
+    if (lh[t])
+      atomicAdd(&hist[t], lh[t]);
 }
 
 // groundTH (TMC3.cpp:183-199): first height bin at which the running count exceeds n/2
@@ -151,7 +172,7 @@ extern "C" int bs_grid_picture_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n,
   double* d_th = reinterpret_cast<double*>(ctx->rs_cnt.as<char>() + th_off);
   BS_HIP(ctx, hipMemsetAsync(cnt, 0, th_off + sizeof(double), st));
 
-  zhist_kernel<<<nblk(n, 256), 256, 0, st>>>(d_xyz, n, make_int3(extent[0], extent[1], extent[2]), bin_height, hist, bad);
+  zhist_kernel<<<nblk(n, 256 * ZH_PER_THREAD), 256, 0, st>>>(d_xyz, n, make_int3(extent[0], extent[1], extent[2]), bin_height, hist, bad);
   ground_th_kernel<<<1, 1, 0, st>>>(hist, nb, n, bin_height, d_th);
   uint32_t* keys_in = ctx->rs_keys_in.as<uint32_t>();
   uint32_t* vals_in = ctx->rs_vals_in.as<uint32_t>();
