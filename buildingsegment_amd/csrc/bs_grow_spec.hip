@@ -219,8 +219,19 @@ __global__ void pull_pass_kernel(int64_t n, int K, const uint32_t* __restrict__ 
                                  const int32_t* __restrict__ neigh, const uint8_t* __restrict__ ps,
                                  const int32_t* __restrict__ base, const int32_t* __restrict__ roff,
                                  const int32_t* __restrict__ radj, int32_t* __restrict__ omega, uint8_t* occ,
-                                 uint8_t* dirty_cur, uint8_t* dirty_next, int* any)
+                                 uint8_t* dirty_cur, uint8_t* dirty_next, uint8_t* bdirty_cur, uint8_t* bdirty_next,
+                                 int4* rec, int quads, int* any)
 {
+  // block-level dirty flag (one per 256 points): late passes touch a few points of a
+  // 50 M cloud, and a pass that reads every point's flag costs 0.18 ms of pure scan
+  __shared__ int block_dirty;
+  if (threadIdx.x == 0) {
+    block_dirty = bdirty_cur[blockIdx.x];
+    bdirty_cur[blockIdx.x] = 0;
+  }
+  __syncthreads();
+  if (!block_dirty)
+    return;
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= n || !dirty_cur[c])
     return;
@@ -233,6 +244,7 @@ __global__ void pull_pass_kernel(int64_t n, int K, const uint32_t* __restrict__ 
       v = j;
   }
   omega[c] = v;
+  reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;  // the growth kernel reads the owner from the record
   const uint32_t m0 = hmask[c];
   const uint8_t want = (m0 != 0 && !ps[c] && v >= (int32_t)c) ? 1 : 0;
   if (want != occ[c]) {
@@ -242,7 +254,9 @@ __global__ void pull_pass_kernel(int64_t n, int K, const uint32_t* __restrict__ 
     while (m) {
       const int t = __ffs(m) - 1;
       m &= m - 1;
-      dirty_next[row[t + 1]] = 1;
+      const int32_t q = row[t + 1];
+      dirty_next[q] = 1;
+      bdirty_next[q >> 8] = 1;
     }
     *any = 1;
   }
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand,
 // (PlaneOut.pad carries the host's per-plane command: 1 = insert, 2 = drop.)
 __global__ __launch_bounds__(VT) void plane_apply_kernel(const PlaneOut* __restrict__ arr, int cnt,
                                                          const int32_t* __restrict__ pool, int32_t* base,
-                                                         uint8_t* ps, uint8_t* dirty)
+                                                         uint8_t* ps, uint8_t* dirty, uint8_t* bdirty)
 {
   const int w = blockIdx.x;
   if (w >= cnt)
@@ -745,6 +759,7 @@ __global__ __launch_bounds__(VT) void plane_apply_kernel(const PlaneOut* __restr
   if (threadIdx.x == 0) {
     ps[o.seed] = ins ? 1 : 0;
     dirty[o.seed] = 1;
+    bdirty[o.seed >> 8] = 1;
   }
   if (!o.keep)
     return;
@@ -755,7 +770,42 @@ __global__ __launch_bounds__(VT) void plane_apply_kernel(const PlaneOut* __restr
     else
       atomicCAS(&base[p], o.seed, INF);
     dirty[p] = 1;
+    bdirty[p >> 8] = 1;
   }
+}
+
+// End of a round: every claim goes back to "free".  A plane's claims are its list
+// (any status: finished, stolen, rolled back) plus -- for a seed that failed at depth
+// 0 -- neighbours of the seed that were claimed in the very step that failed and
+// never reached the list.  Replaces a full pass over all records per round.
+__global__ __launch_bounds__(VT) void reset_tags_kernel(const PlaneOut* __restrict__ out, int ncand,
+                                                        const int32_t* __restrict__ pool, int4* rec, int quads,
+                                                        const int32_t* __restrict__ neigh, int K)
+{
+  const int w = blockIdx.x;
+  if (w >= ncand)
+    return;
+  const PlaneOut o = out[w];
+  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT) {
+    int32_t* tg = rec_tag(rec, quads, pool[o.list_off + t]);
+    if (*tg == o.seed)
+      *tg = INF;
+  }
+  if (threadIdx.x >= 1 && threadIdx.x < K) {
+    int32_t* tg = rec_tag(rec, quads, neigh[(int64_t)o.seed * K + threadIdx.x]);
+    if (*tg == o.seed)
+      *tg = INF;
+  }
+}
+
+// BS_VERIFY=1: do the incrementally maintained records equal a full refresh?
+__global__ void verify_records_kernel(const int32_t* __restrict__ omega, int4* rec, int quads, int64_t n, int* nbad)
+{
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  if (reinterpret_cast<int32_t*>(rec + i * quads)[3] != omega[i] || *rec_tag(rec, quads, i) != INF)
+    atomicAdd(nbad, 1);
 }
 
 __global__ __launch_bounds__(VT) void validate2_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
@@ -857,7 +907,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // aux layout (int32 units): misc[1024] | hmask | omega | base | dead | cand | roff(n+2) | rpos | seeds |
   //                            (u8) flags | ps | occ | dirty0 | dirty1 | PlaneOut[MAX_WAVES + MAX_PENDING] | CopyDesc[]
   const size_t n_i32 = (size_t)(7 * n + planes_cap + 1024 + 128);
-  const size_t aux_bytes = sizeof(int32_t) * n_i32 + (size_t)5 * n + 8192 +
+  const size_t nb256 = (size_t)((n + 255) / 256);
+  const size_t aux_bytes = sizeof(int32_t) * n_i32 + (size_t)5 * n + 2 * nb256 + 8192 +
                            sizeof(PlaneOut) * (MAX_WAVES + MAX_PENDING) + sizeof(CopyDesc) * (MAX_WAVES + MAX_PENDING);
   BS_HIP(ctx, ctx->rg_aux.reserve(aux_bytes));
   BS_HIP(ctx, ctx->rg_stack.reserve(sizeof(int32_t) * pool_cap));
@@ -877,7 +928,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   uint8_t* occ = ps + n;
   uint8_t* dirty0 = occ + n;
   uint8_t* dirty1 = dirty0 + n;
-  PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(dirty1 + n) + 255) & ~(uintptr_t)255);
+  uint8_t* bdirty0 = dirty1 + n;  // one flag per 256 points
+  uint8_t* bdirty1 = bdirty0 + nb256;
+  PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(bdirty1 + nb256) + 255) & ~(uintptr_t)255);
   PlaneOut* d_pend = d_out + MAX_WAVES;
   CopyDesc* d_copy = (CopyDesc*)(d_pend + MAX_PENDING);
   int32_t* radj = ctx->rg_radj.as<int32_t>();
@@ -931,19 +984,24 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   BS_HIP(ctx, hipMemsetAsync(occ, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(dirty0, 1, n, st));
   BS_HIP(ctx, hipMemsetAsync(dirty1, 0, n, st));
+  BS_HIP(ctx, hipMemsetAsync(bdirty0, 1, nb256, st));
+  BS_HIP(ctx, hipMemsetAsync(bdirty1, 0, nb256, st));
   uint8_t* dcur = dirty0;
   uint8_t* dnext = dirty1;
+  uint8_t* bcur = bdirty0;
+  uint8_t* bnext = bdirty1;
   int64_t passes = 0;
   auto propagate = [&]() -> int {
     for (int it = 0; it < 1000000; it++) {
       BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
       pull_pass_kernel<<<nblk(n, 256), 256, 0, st>>>(n, K, hmask, d_neigh, ps, base, roff, radj, omega, occ, dcur,
-                                                     dnext, d_misc);
+                                                     dnext, bcur, bnext, rec, quads, d_misc);
       int any = 0;
       BS_HIP(ctx, hipMemcpyAsync(&any, d_misc, sizeof any, hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
       passes++;
       std::swap(dcur, dnext);  // dcur now holds the newly dirtied points (the old dcur was cleared by the pass)
+      std::swap(bcur, bnext);
       if (!any) {
         if (getenv("BS_VERIFY")) {
           BS_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, sizeof(int), st));
@@ -979,6 +1037,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0, grow_launches = 0;
   double grow_ms = 0.0;
   bool timed_round = false;
+  const bool force_full_refresh = getenv("BS_FULL_REFRESH") != nullptr;  // debugging aid: the pre-incremental behaviour
+  bool full_refresh = force_full_refresh;
   int32_t F = 0;
   size_t sel_tmp = 0;
   {
@@ -1041,7 +1101,22 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       BS_HIP(ctx, hipMemcpyAsync(d_pend, pending.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
     if (ncand > 0) {
       // grow them concurrently against the current owners
-      refresh_records_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, rec, quads, n);
+      // Records are maintained incrementally: pull_pass_kernel writes every owner change
+      // into the record and reset_tags_kernel frees the claims of the previous round.  A
+      // full pass is only needed after a pool exhaustion (claims of a plane that ran out
+      // of memory between claiming and listing are not recorded anywhere).
+      if (full_refresh) {
+        refresh_records_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, rec, quads, n);
+        full_refresh = force_full_refresh;
+      } else if (getenv("BS_VERIFY")) {
+        BS_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, sizeof(int), st));
+        verify_records_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, rec, quads, n, d_misc + 3);
+        int nb = 0;
+        BS_HIP(ctx, hipMemcpyAsync(&nb, d_misc + 3, sizeof nb, hipMemcpyDeviceToHost, st));
+        BS_HIP(ctx, hipStreamSynchronize(st));
+        if (nb)
+          fprintf(stderr, "[bs] VERIFY: %d records differ from a full refresh (round %ld)\n", nb, (long)rounds);
+      }
       BS_HIP(ctx, hipMemsetAsync(dead, 0, sizeof(int32_t) * n, st));
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
       (void)hipEventRecord(ctx->ev[6], st);
@@ -1053,8 +1128,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       grow_launches++;
       timed_round = true;
       validate1_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n);
+      reset_tags_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, d_neigh, K);
       // insert the finished planes and let the owners settle
-      plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
+      plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur);
       rc = propagate();
       if (rc != BS_OK)
         return rc;
@@ -1093,6 +1169,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         first_bad = std::min(first_bad, o.seed);
       if (w == 0 && o.status == ST_NOMEM)
         nomem_lowest = true;
+      if (o.status == ST_NOMEM)
+        full_refresh = true;  // its last claims may be neither listed nor reset
     }
     for (int w = 0; w < npend; w++)
       if (!h_pend[w].consistent)
@@ -1183,11 +1261,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     if (dropped) {
       if (ncand) {
         BS_HIP(ctx, hipMemcpyAsync(d_out, h_out.data(), sizeof(PlaneOut) * ncand, hipMemcpyHostToDevice, st));
-        plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur);
+        plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur);
       }
       if (npend) {
         BS_HIP(ctx, hipMemcpyAsync(d_pend, h_pend.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
-        plane_apply_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, base, ps, dcur);
+        plane_apply_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, base, ps, dcur, bcur);
       }
       rc = propagate();
       if (rc != BS_OK)
