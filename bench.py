@@ -40,25 +40,31 @@ def parse():
     ap.add_argument("--k", type=int, default=0, help="neighbour-list length (0 = workload default)")
     ap.add_argument("--rg-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 control "
+                         "flow with several ranks sharing one GPU)")
     ap.add_argument("--secondary", default="urban_10m",
                     help="second workload measured live and reported under 'secondary' ('' = none)")
     return ap.parse_args()
 
 
 def make_cloud(name: str, rank: int):
+    """The named BASELINE workload.  Every rank segments its own copy of the SAME cloud (the
+    config names one seed): weak scaling then measures the system, not the luck of a seed --
+    the façade's critical chain varies by 40 % between seeds."""
     from buildingsegment_amd import synth
     if name == "facade_1m":
-        return synth.facade(n_side=1000, seed=2 + 100 * rank), 16
+        return synth.facade(n_side=1000, seed=2), 16
     if name == "urban_10m":
-        return synth.urban(10_000_000, seed=3 + 100 * rank), 32
+        return synth.urban(10_000_000, seed=3), 32
     if name == "urban_50m":
-        return synth.urban(50_000_000, seed=4 + 100 * rank), 16
+        return synth.urban(50_000_000, seed=4), 16
     if name == "urban_2m":
-        return synth.urban(2_000_000, seed=3 + 100 * rank), 16
+        return synth.urban(2_000_000, seed=3), 16
     if name == "plane_cube_100k":
-        return synth.plane_cube(seed=1 + 100 * rank), 15
+        return synth.plane_cube(seed=1), 15
     if name == "uniform_1m":
-        return synth.uniform(1_000_000, seed=6 + 100 * rank), 16
+        return synth.uniform(1_000_000, seed=6), 16
     raise ValueError(name)
 
 
@@ -102,8 +108,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":  # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -149,7 +160,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = ctx.timings()
@@ -237,7 +248,7 @@ def main():
         fence()
         el2 = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el2], dtype=torch.float64, device=dev)
+            t = torch.tensor([el2], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
         tm2 = ctx.timings()
