@@ -563,45 +563,62 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       unsigned long long am = 0;
       int gstar = -1;
       bool ok = false;
-      for (int gg = 0; cm != 0 && gg < ngv; gg++) {  // cm == 0: every pending call is empty
-        const unsigned long long gm = gmask0 << (gg * KC);
-        if (cm & gm) {
-          // Claim protocol for call gg.  tag[p] = seed of the in-flight plane
-          // holding p.  A sequentially earlier plane always wins (atomicMin); a
-          // plane that loses a point it had accepted is marked dead, and points
-          // held by dead planes can be reclaimed.  Every "taken" decision that
-          // rests on a non-final owner is logged and re-checked after the round.
-          if (g == gg && contender) {
-            int32_t* tp = rec_tag(rec, Q, cand_id);
-            int cur_tag = tg;
-            bool mine = false;
-            for (int tries = 0; tries < 8 && !ok && !assume && !mine; tries++) {
-              if (cur_tag < seed) {            // an earlier in-flight plane holds it ...
-                if (ld_i32(dead + cur_tag)) {  // ... which is already invalid: reclaim
-                  const int old = atomicCAS(tp, cur_tag, seed);
-                  if (old == cur_tag)
-                    ok = true;
-                  else
-                    cur_tag = old;
-                } else {
-                  assume = true;
+      if (cm != 0) {  // cm == 0: every pending call is empty
+        // first call with a contender; its contenders are normally all free or held by a later
+        // plane (tag > seed): they simply claim, and the walk is over without a loop
+        const int g1 = (__ffsll(cm) - 1) / KC;
+        const unsigned long long gm1 = gmask0 << (g1 * KC);
+        const unsigned long long earlier = __ballot(contender && tg < seed);  // held by an earlier in-flight plane
+        if ((earlier & gm1) == 0) {
+          ok = contender && g == g1;
+          if (ok) {
+            pend_old = atomicMin(rec_tag(rec, Q, cand_id), seed);
+            pend = true;
+          }
+          am = cm & gm1;
+          gstar = g1;
+        } else {
+        for (int gg = g1; gg < ngv; gg++) {
+          const unsigned long long gm = gmask0 << (gg * KC);
+          if (cm & gm) {
+            // Claim protocol for call gg.  tag[p] = seed of the in-flight plane
+            // holding p.  A sequentially earlier plane always wins (atomicMin); a
+            // plane that loses a point it had accepted is marked dead, and points
+            // held by dead planes can be reclaimed.  Every "taken" decision that
+            // rests on a non-final owner is logged and re-checked after the round.
+            if (g == gg && contender) {
+              int32_t* tp = rec_tag(rec, Q, cand_id);
+              int cur_tag = tg;
+              bool mine = false;
+              for (int tries = 0; tries < 8 && !ok && !assume && !mine; tries++) {
+                if (cur_tag < seed) {            // an earlier in-flight plane holds it ...
+                  if (ld_i32(dead + cur_tag)) {  // ... which is already invalid: reclaim
+                    const int old = atomicCAS(tp, cur_tag, seed);
+                    if (old == cur_tag)
+                      ok = true;
+                    else
+                      cur_tag = old;
+                  } else {
+                    assume = true;
+                  }
+                } else if (cur_tag == seed) {
+                  mine = true;
+                } else {  // free, or held by a later plane: claim, verify next call
+                  pend_old = atomicMin(tp, seed);
+                  pend = true;
+                  ok = true;
                 }
-              } else if (cur_tag == seed) {
-                mine = true;
-              } else {  // free, or held by a later plane: claim, verify next call
-                pend_old = atomicMin(tp, seed);
-                pend = true;
-                ok = true;
               }
+              if (!ok && !mine)
+                assume = true;
             }
-            if (!ok && !mine)
-              assume = true;
+            am = __ballot(ok);
+            if (am) {
+              gstar = gg;
+              break;
+            }
           }
-          am = __ballot(ok);
-          if (am) {
-            gstar = gg;
-            break;
-          }
+        }
         }
       }
       const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed
