@@ -102,6 +102,13 @@ __device__ inline int ld_i32(const int32_t* p)
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// wave-wide vote straight from a condition (HIP's __ballot(int) first materialises the
+// predicate as 0/1 in a VGPR and compares it again: two VALU ops per vote)
+__device__ inline unsigned long long ballot64(bool pred)
+{
+  return __builtin_amdgcn_ballot_w64(pred);
+}
+
 __device__ inline int readlane_i32(int v, int lane)
 {
   return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
@@ -551,14 +558,14 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       if (pend && pend_old > seed && pend_old != INF)
         dead[pend_old] = seed + 1;  // took it from a later plane: that plane is invalid (value: thief + 1)
       pend = false;
-      if (killed || __ballot(lost)) {
+      if (killed || ballot64(lost)) {
         status = ST_STOLEN;
         break;
       }
       // side-effect free classification
       bool assume = geo && own < seed && !(own < a.F);  // kept by an earlier, not yet final attempt
       const bool contender = geo && !(own < seed);
-      const unsigned long long cm = __ballot(contender);
+      const unsigned long long cm = ballot64(contender);
       // ---- walk the pending calls in order: consume empty ones, stop at the first that accepts ----
       unsigned long long am = 0;
       int gstar = -1;
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         // plane (tag > seed): they simply claim, and the walk is over without a loop
         const int g1 = (__ffsll(cm) - 1) / KC;
         const unsigned long long gm1 = gmask0 << (g1 * KC);
-        const unsigned long long earlier = __ballot(contender && tg < seed);  // held by an earlier in-flight plane
+        const unsigned long long earlier = ballot64(contender && tg < seed);  // held by an earlier in-flight plane
         if ((earlier & gm1) == 0) {
           ok = contender && g == g1;
           if (ok) {
@@ -612,7 +619,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
               if (!ok && !mine)
                 assume = true;
             }
-            am = __ballot(ok);
+            am = ballot64(ok);
             if (am) {
               gstar = gg;
               break;
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed
       steps += last + 1;
       // assumptions made by consumed calls
-      const unsigned long long lm = __ballot(assume && g <= last);
+      const unsigned long long lm = ballot64(assume && g <= last);
       const int lcnt = __popcll(lm);
       if (lcnt) {
         if (!slab_ensure(pool, log, logn, logn + lcnt, lane)) {
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     dead[pend_old] = seed + 1;
   if (status == ST_DONE) {
     const bool lost = pend && pend_old <= seed;
-    if (__ballot(lost))
+    if (ballot64(lost))
       status = ST_STOLEN;
   }
   if (status != ST_STOLEN || attempt >= MAX_RETRY || ln > retry_max_list)

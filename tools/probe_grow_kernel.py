@@ -27,9 +27,9 @@ PATCHES = [
      '    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};\n    long long ncalls = 0, nexp = 0;\n    long long tlast = clock64();\n'
      '    for (;;) {\n      if (sp == 0)\n        break;\n      if (++iters > iter_cap) {\n        status = ST_WATCHDOG;\n        break;\n      }\n'
      '      ncalls++;\n      PROBE(7);\n'),
-    ('      if (need_state) {\n        const double nrm', '      PROBE(0);\n      if (need_state) {\n        const double nrm'),
-    ('        need_state = false;\n      }\n      bool geo = false;',
-     '        need_state = false;\n      }\n      PROBE(1);\n      __builtin_amdgcn_s_waitcnt(0x0F70);\n      PROBE(2);\n      bool geo = false;'),
+    ('      if (need_state)\n        update_state();\n      bool geo = false;',
+     '      PROBE(0);\n      if (need_state)\n        update_state();\n      PROBE(1);\n      __builtin_amdgcn_s_waitcnt(0x0F70);\n'
+     '      PROBE(2);\n      bool geo = false;'),
     ('      const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed\n',
      '      PROBE(3);\n      const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed\n'),
     ('      if (gstar < 0)\n        continue;\n', '      PROBE(4);\n      if (gstar < 0)\n        continue;\n      nexp++;\n'),
