@@ -94,7 +94,7 @@ struct Pool {
 
 struct Slab {
   int64_t off;
-  int64_t cap;
+  int32_t cap;  // entries (int32); a slab never exceeds 2^31 - 4 of them
 };
 
 __device__ inline int ld_i32(const int32_t* p)
@@ -123,15 +123,19 @@ __device__ inline double readlane_f64(double v, int lane)
 }
 
 // wave-cooperative "realloc": make room for need entries, keeping used ones
-__device__ inline bool slab_ensure(const Pool& pool, Slab& s, int64_t used, int64_t need, int lane)
+__device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int64_t need, int lane)
 {
   if (need <= s.cap)
     return true;
-  int64_t ncap = s.cap * 2;
+  if (need > 0x7ffffff0ll)
+    return false;
+  int64_t ncap = (int64_t)s.cap * 2;
   if (ncap < need)
     ncap = need;
   if (ncap < 2048)
     ncap = 2048;
+  if (ncap > 0x7ffffff0ll)
+    ncap = 0x7ffffff0ll;
   ncap = (ncap + 3) & ~(int64_t)3;  // keep slab offsets 16-byte aligned (int4 stack slots)
   unsigned long long off = 0;
   if (lane == 0)
@@ -140,10 +144,10 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int64_t used, int6
         (uint32_t)readlane_i32((int)(off & 0xffffffffu), 0);
   if (off + (unsigned long long)ncap > pool.cap)
     return false;
-  for (int64_t t = lane; t < used; t += 64)
+  for (int32_t t = lane; t < used; t += 64)
     pool.base[off + t] = ld_i32(pool.base + s.off + t);
   s.off = (int64_t)off;
-  s.cap = ncap;
+  s.cap = (int32_t)ncap;
   return true;
 }
 
@@ -407,7 +411,6 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
   // 32-bit bookkeeping (n < 2^31): 64-bit scalar arithmetic doubles the SALU work of every call
   int ln = 1, sp = 0, lds_lo = 0, logn = 0;
-  int64_t steps = 0;
   uint32_t iters = 0;
   const uint32_t iter_cap = step_cap > 0xFFFFFFF0ll ? 0xFFFFFFF0u : (uint32_t)step_cap;
   int status = ST_DONE;
@@ -629,7 +632,6 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         }
       }
       const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed
-      steps += last + 1;
       // assumptions made by consumed calls
       const unsigned long long lm = ballot64(assume && g <= last);
       const int lcnt = __popcll(lm);
@@ -655,7 +657,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       if (gstar < 0)
         continue;
       // ---- expand call gstar: :231-255 ----
-      if (!slab_ensure(pool, list, ln, ln + cnt, lane) || !slab_ensure(pool, stack, (int64_t)sp * KC, (int64_t)(sp + cnt) * KC, lane)) {
+      if (!slab_ensure(pool, list, ln, ln + cnt, lane) ||
+          !slab_ensure(pool, stack, sp > 0x7ffffff0 / KC ? 0x7ffffff0 : sp * KC, (int64_t)(sp + cnt) * KC, lane)) {
         status = ST_NOMEM;
         break;
       }
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     o.list_n = ln;
     o.log_off = log.off;
     o.log_n = logn;
-    o.steps = steps;
+    o.steps = iters;  // wave steps (a multi-pop counts once)
     o.seed = seed;
     o.status = status;
     o.keep = (status == ST_DONE && ln > a.th_count) ? 1 : 0;
