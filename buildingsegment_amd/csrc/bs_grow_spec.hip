@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
               bool mine = false;
               for (int tries = 0; tries < 8 && !ok && !assume && !mine; tries++) {
                 if (cur_tag < seed) {            // an earlier in-flight plane holds it ...
-                  if (ld_i32(dead + cur_tag)) {  // ... which is already invalid: reclaim
+                  if (ld_i32(dead + cur_tag) < 0) {  // ... which has given up for this launch: reclaim
                     const int old = atomicCAS(tp, cur_tag, seed);
                     if (old == cur_tag)
                       ok = true;
@@ -720,6 +720,18 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   // ... and come back to life: marks written from here on concern the new incarnation
   __hip_atomic_store(dead + seed, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }  // attempt loop
+  // dead[] protocol.  > 0: "a thief (value - 1) took one of my points" -- written by thieves,
+  // read by the victim, which may come back to life in this launch (re-growth above) and claim
+  // the very same points again under the very same tag value.  Reclaiming from such a plane
+  // is an ABA race (read the flag, the victim resurrects and re-claims, then the CAS on the
+  // tag succeeds against the LIVE incarnation, which later takes the point back and holds
+  // it twice -- found by fuzzing as a validated plane with duplicated list entries).  Only a
+  // plane that has given up for this launch is reclaimable: it says so itself, here, with
+  // a negative value, and never claims again.
+  if (lane == 0 && status == ST_STOLEN) {
+    const int t = ld_i32(dead + seed);
+    __hip_atomic_store(dead + seed, t > 0 ? -t : (t == 0 ? -0x40000000 : t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (lane == 0) {
     PlaneOut o;
     o.normal[0] = cnx;
@@ -738,7 +750,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     o.keep = (status == ST_DONE && ln > a.th_count) ? 1 : 0;
     o.consistent = 0;
     o.pad = 0;
-    o.thief = ld_i32(dead + seed) - 1;
+    const int dflag = ld_i32(dead + seed);
+    o.thief = (dflag < 0 ? -dflag : dflag) - 1;
     o.pad2 = 0;
     out[w] = o;
   }
