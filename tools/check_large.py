@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size exactness check of a bench workload against the CPU oracle (GPU box;
-takes minutes: the oracle is single threaded).  usage: check_large.py <workload>"""
+takes minutes: the oracle is single threaded).  usage: check_large.py <workload> [repeats of the growth]"""
 import os
 import sys
 import time
@@ -40,4 +40,20 @@ if ok and planes:
         np.array_equal(np.stack([q.normal for q in planes]), opl["normal"]) and \
         np.array_equal(np.stack([q.center for q in planes]), opl["center"])
 print("labels/planes equal", ok, "planes", len(planes), "labelled", int((plane_idx > 0).sum()), flush=True)
-sys.exit(0 if ok else 1)
+# the speculative grower's schedule is timing dependent: repeat the growth (argv[2] times) against
+# the same oracle result
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+nbad = 0
+for r in range(reps):
+    pi, pls = ctx.region_grow(xyz, onormals, oneigh, api.default_params(k=k))
+    okr = np.array_equal(pi, opi) and len(pls) == len(opl["id"])
+    if okr and pls:
+        okr = np.array_equal(np.concatenate([q.pointIdx for q in pls]), opl["point_idx"]) and \
+            np.array_equal(np.stack([q.normal for q in pls]), opl["normal"]) and \
+            np.array_equal(np.stack([q.center for q in pls]), opl["center"])
+    nbad += not okr
+    if (r + 1) % 5 == 0 or not okr:
+        print(f"  repeated growth {r + 1}/{reps}: mismatching runs so far {nbad}", flush=True)
+if reps:
+    print("repeated growth:", reps, "runs,", nbad, "mismatches", flush=True)
+sys.exit(0 if ok and nbad == 0 else 1)
