@@ -491,6 +491,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       lds_stack[lane] = reinterpret_cast<const int32_t*>(srec + 4)[lane];
     sp = 1;
     bool depth0 = true;
+    int stack_entries = stack.cap / KC;  // LIFO entries the stack slab holds
     need_state = false;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (;;) {
@@ -657,10 +658,13 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       if (gstar < 0)
         continue;
       // ---- expand call gstar: :231-255 ----
-      if (!slab_ensure(pool, list, ln, ln + cnt, lane) ||
-          !slab_ensure(pool, stack, sp > 0x7ffffff0 / KC ? 0x7ffffff0 : sp * KC, (int64_t)(sp + cnt) * KC, lane)) {
-        status = ST_NOMEM;
-        break;
+      if (ln + cnt > list.cap || sp + cnt > stack_entries) {  // one test for both slabs; growing them is rare
+        if (!slab_ensure(pool, list, ln, ln + cnt, lane) ||
+            !slab_ensure(pool, stack, sp > 0x7ffffff0 / KC ? 0x7ffffff0 : sp * KC, (int64_t)(sp + cnt) * KC, lane)) {
+          status = ST_NOMEM;
+          break;
+        }
+        stack_entries = stack.cap / KC;
       }
       const int rank = __popcll(am & ((1ull << lane) - 1ull));
       if (ok)
