@@ -495,9 +495,9 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     need_state = false;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (;;) {
-      if (sp == 0)
+      if (__builtin_expect(sp == 0, 0))
         break;
-      if (++iters > iter_cap) {
+      if (__builtin_expect(++iters > iter_cap, 0)) {
         status = ST_WATCHDOG;
         break;
       }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       const bool valid = e >= 0;
       const int ngv = (sp < NG) ? sp : NG;            // valid groups
       const int need_lo = (sp - NG > 0) ? sp - NG : 0;
-      if (need_lo < lds_lo) {  // wave-uniform
+      if (__builtin_expect(need_lo < lds_lo, 0)) {  // wave-uniform, rare
         const int new_lo = lds_lo > LDS_REFILL ? lds_lo - LDS_REFILL : 0;
         const int nw = (lds_lo - new_lo) * KC;
         for (int t = lane; t < nw; t += 64) {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       // three 64-bit integer divisions) is evaluated HERE, between the issue of the
       // gather loads above and their first use below: ~500 cycles of arithmetic
       // that hide behind the memory latency instead of preceding it.
-      if (need_state)
+      if (__builtin_expect(need_state, 1))
         update_state();
       bool geo = false;
       if (valid && act && tg != seed) {  // tg == seed: already labelled by this plane
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       if (pend && pend_old > seed && pend_old != INF)
         dead[pend_old] = seed + 1;  // took it from a later plane: that plane is invalid (value: thief + 1)
       pend = false;
-      if (killed || ballot64(lost)) {
+      if (__builtin_expect(killed || ballot64(lost), 0)) {
         status = ST_STOLEN;
         break;
       }
@@ -574,13 +574,13 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       unsigned long long am = 0;
       int gstar = -1;
       bool ok = false;
-      if (cm != 0) {  // cm == 0: every pending call is empty
+      if (__builtin_expect(cm != 0, 1)) {  // cm == 0: every pending call is empty
         // first call with a contender; its contenders are normally all free or held by a later
         // plane (tag > seed): they simply claim, and the walk is over without a loop
         const int g1 = (__ffsll(cm) - 1) / KC;
         const unsigned long long gm1 = gmask0 << (g1 * KC);
         const unsigned long long earlier = ballot64(contender && tg < seed);  // held by an earlier in-flight plane
-        if ((earlier & gm1) == 0) {
+        if (__builtin_expect((earlier & gm1) == 0, 1)) {
           ok = contender && g == g1;
           if (ok) {
             pend_old = atomicMin(rec_tag(rec, Q, cand_id), seed);
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       // assumptions made by consumed calls
       const unsigned long long lm = ballot64(assume && g <= last);
       const int lcnt = __popcll(lm);
-      if (lcnt) {
+      if (__builtin_expect(lcnt != 0, 0)) {
         if (!slab_ensure(pool, log, logn, logn + lcnt, lane)) {
           status = ST_NOMEM;
           break;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         logn += lcnt;
       }
       const int cnt = __popcll(am);
-      if (depth0 && cnt < nc) {
+      if (__builtin_expect(depth0 && cnt < nc, 0)) {
         status = ST_FAILED0;  // under speculation this seed is (currently) an orphan maker
         break;
       }
@@ -655,10 +655,10 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       sp -= last + 1;
       if (sp < lds_lo)
         lds_lo = sp;  // entries below are only in HBM; new pushes land in LDS again
-      if (gstar < 0)
+      if (__builtin_expect(gstar < 0, 0))
         continue;
       // ---- expand call gstar: :231-255 ----
-      if (ln + cnt > list.cap || sp + cnt > stack_entries) {  // one test for both slabs; growing them is rare
+      if (__builtin_expect(ln + cnt > list.cap || sp + cnt > stack_entries, 0)) {  // one test for both slabs; growing them is rare
         if (!slab_ensure(pool, list, ln, ln + cnt, lane) ||
             !slab_ensure(pool, stack, sp > 0x7ffffff0 / KC ? 0x7ffffff0 : sp * KC, (int64_t)(sp + cnt) * KC, lane)) {
           status = ST_NOMEM;
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         }
       }
       sp += cnt;
-      if (sp - lds_lo > LDS_STACK)
+      if (__builtin_expect(sp - lds_lo > LDS_STACK, 0))
         lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)
     }
   }
