@@ -23,25 +23,30 @@ PATCHES = [
     ('// wave-cooperative "realloc"',
      '__device__ unsigned long long g_prof[16];\n#define PROBE(i) do { const long long _t = clock64(); pacc[i] += _t - tlast; '
      'tlast = _t; } while (0)\n\n// wave-cooperative "realloc"'),
-    ('    for (;;) {\n      if (sp == 0)\n        break;\n      if (++iters > iter_cap) {\n        status = ST_WATCHDOG;\n        break;\n      }\n',
+    ('    auto step = [&](auto mode) -> int {\n      if (__builtin_expect(sp == 0, 0))\n        return 2;\n'
+     '      if (__builtin_expect(++iters > iter_cap, 0)) {\n        status = ST_WATCHDOG;\n        return 2;\n      }\n',
      '    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};\n    long long ncalls = 0, nexp = 0;\n    long long tlast = clock64();\n'
-     '    for (;;) {\n      if (sp == 0)\n        break;\n      if (++iters > iter_cap) {\n        status = ST_WATCHDOG;\n        break;\n      }\n'
+     '    auto step = [&](auto mode) -> int {\n      if (__builtin_expect(sp == 0, 0))\n        return 2;\n'
+     '      if (__builtin_expect(++iters > iter_cap, 0)) {\n        status = ST_WATCHDOG;\n        return 2;\n      }\n'
      '      ncalls++;\n      PROBE(7);\n'),
-    ('      if (need_state)\n        update_state();\n      bool geo = false;',
-     '      PROBE(0);\n      if (need_state)\n        update_state();\n      PROBE(1);\n      __builtin_amdgcn_s_waitcnt(0x0F70);\n'
-     '      PROBE(2);\n      bool geo = false;'),
+    ('      if constexpr (decltype(mode)::value == 1)\n', '      PROBE(0);\n      if constexpr (decltype(mode)::value == 1)\n'),
+    ('          update_state();\n      }\n      bool geo = false;',
+     '          update_state();\n      }\n      PROBE(1);\n      __builtin_amdgcn_s_waitcnt(0x0F70);\n      PROBE(2);\n      bool geo = false;'),
     ('      const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed\n',
      '      PROBE(3);\n      const int last = gstar >= 0 ? gstar : ngv - 1;  // calls 0..last are consumed\n'),
-    ('      if (gstar < 0)\n        continue;\n', '      PROBE(4);\n      if (gstar < 0)\n        continue;\n      nexp++;\n'),
+    ('      if (__builtin_expect(gstar < 0, 0))\n        return 0;\n',
+     '      PROBE(4);\n      if (__builtin_expect(gstar < 0, 0))\n        return 0;\n      nexp++;\n'),
     ('      ln += cnt;\n      need_state = true;', '      ln += cnt;\n      PROBE(5);\n      need_state = true;'),
-    ('        lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)\n    }\n',
-     '        lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)\n      PROBE(6);\n    }\n'
+    ('        lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)\n      return 1;\n    };\n',
+     '        lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)\n      PROBE(6);\n      return 1;\n    };\n'),
+    ('      while (step(std::integral_constant<int, 2>{}) != 2) {\n      }\n    }\n',
+     '      while (step(std::integral_constant<int, 2>{}) != 2) {\n      }\n    }\n'
      '    if (lane == 0 && ln > 20000) {\n      for (int i = 0; i < 8; i++)\n        atomicAdd(&g_prof[i], (unsigned long long)pacc[i]);\n'
      '      atomicAdd(&g_prof[8], (unsigned long long)ncalls);\n      atomicAdd(&g_prof[9], (unsigned long long)nexp);\n    }\n'),
     ('    if (getenv("BS_DEBUG")) {\n      int cnt[6]',
      '    if (getenv("BS_DEBUG")) {\n      unsigned long long hp[16];\n      hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp));\n'
-     '      fprintf(stderr, "[prof] calls=%llu exp=%llu | src+issue=%llu state=%llu wait=%llu geo+walk=%llu bookA=%llu listS=%llu '
-     'push=%llu top=%llu (counter units per call, cumulative)\\n", hp[8], hp[9], hp[0] / (hp[8] + 1), hp[1] / (hp[8] + 1), '
+     '      fprintf(stderr, "[prof] steps=%llu expansions=%llu | src+issue=%llu state=%llu wait=%llu geo+walk=%llu bookA=%llu listS=%llu '
+     'push=%llu top=%llu (counter units per step, cumulative over rounds)\\n", hp[8], hp[9], hp[0] / (hp[8] + 1), hp[1] / (hp[8] + 1), '
      'hp[2] / (hp[8] + 1), hp[3] / (hp[8] + 1), hp[4] / (hp[8] + 1), hp[5] / (hp[8] + 1), hp[6] / (hp[8] + 1), hp[7] / (hp[8] + 1));\n'
      '      int cnt[6]'),
 ]
