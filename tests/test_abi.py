@@ -58,3 +58,8 @@ def test_product_never_imports_oracle():
     for f in os.listdir(os.path.join(ROOT, "host")):
         if f.endswith((".h", ".cpp", ".hpp")):
             assert "oracle" not in open(os.path.join(ROOT, "host", f), errors="ignore").read()
+    # developer tools outside tests/ never import it either (checkers that do live in tests/tools/)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert "import oracle" not in txt and "from oracle" not in txt, f"tools/{f} uses the oracle"

@@ -298,7 +298,7 @@ def test_device_pre_and_post_processing(gpu_ctx, oracle):
 
 
 def test_regression_fuzz_7_106_unsettled_claims(gpu_ctx, oracle):
-    """Found by tools/fuzz_parity.py: k=4, cos_th=0 on a curved sheet gives ~18 000
+    """Found by tests/tools/fuzz_parity.py: k=4, cos_th=0 on a curved sheet gives ~18 000
     plane attempts (10 commit).  A plane that failed at depth 0 left its optimistic
     claims unsettled, its victim reclaimed the point and held it twice while passing
     validation.  Must be exact, repeatedly, at full concurrency."""
@@ -351,14 +351,14 @@ def test_center_div_device_exact(gpu_ctx):
 
 @pytest.mark.gpu
 def test_fuzz_negative_coordinates_and_noisy_normals():
-    """40 differential fuzz cases (tools/fuzz_parity.py: negative coordinates,
+    """40 differential fuzz cases (tests/tools/fuzz_parity.py: negative coordinates,
     perturbed non-unit normals, tiny planes, both grow modes).  Plane normals and
     centres are part of the comparison: an inexact plane-centre division that
     still produced the right labels was caught by exactly these cases."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "40", "--seed", "4242"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_parity.py"), "--cases", "40", "--seed", "4242"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "40 cases, 0 mismatches" in out.stdout
@@ -375,7 +375,7 @@ def test_regression_fuzz_2718_16_reclaim_aba():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "17", "--seed", "2718",
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_parity.py"), "--cases", "17", "--seed", "2718",
                           "--only", "16", "--repeat", "25"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "0 mismatches" in out.stdout

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Debug aid: rerun one dumped fuzz case (tools/fuzz_parity.py --dump) until the device's planes
+"""Debug aid: rerun one dumped fuzz case (tests/tools/fuzz_parity.py --dump) until the device's planes
 differ from the oracle's and print where the first plane list diverges."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from buildingsegment_amd import api  # noqa: E402
 from oracle import oracle as O  # noqa: E402

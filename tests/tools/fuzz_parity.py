@@ -4,7 +4,7 @@
 Random small clouds (surfaces, blobs, lattices with heavy ties), random k,
 thresholds, normal noise and point orders; every stage is compared bit for bit
 (neighbour indices, normals, labels, plane lists) in both region-grow modes.
-usage: python tools/fuzz_parity.py [--cases N] [--seed S] [--log FILE]
+usage: python tests/tools/fuzz_parity.py [--cases N] [--seed S] [--log FILE]
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the device-resident 2-D raster (bs_grid_picture_dev) on an urban cloud and
-the CPU oracle beside it.  usage: python tools/raster_bench.py [n_points] [reps]"""
+the CPU oracle beside it.  usage: python tests/tools/raster_bench.py [n_points] [reps]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 torch.zeros(1, device="cuda")
 from buildingsegment_amd import api, synth  # noqa: E402
