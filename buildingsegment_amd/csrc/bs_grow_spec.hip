@@ -298,7 +298,8 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
 // ---- plane-attempt candidates -------------------------------------------------
 __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
                                  int64_t n, int32_t F, const uint8_t* __restrict__ ps,
-                                 const int32_t* __restrict__ omega, uint8_t* __restrict__ flags, int32_t* min_idx)
+                                 const int32_t* __restrict__ omega, uint8_t* __restrict__ flags, int32_t* min_idx,
+                                 int32_t* __restrict__ cand_out, int32_t* cand_count)
 {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n)
@@ -315,6 +316,8 @@ __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int32
     flags[i] = c ? 1 : 0;
   if (c && min_idx)
     atomicMin(min_idx, (int32_t)i);
+  if (c && cand_out)  // candidates are sparse: appended unordered, the (few) entries are sorted afterwards
+    cand_out[atomicAdd(cand_count, 1)] = (int32_t)i;
 }
 
 // ---- (b) speculative plane growth: one wavefront per candidate seed -------------
@@ -1114,8 +1117,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int32_t F = 0;
   size_t sel_tmp = 0;
   {
-    hipcub::CountingInputIterator<int32_t> it(0);
-    BS_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, sel_tmp, it, flags, d_cand, d_misc + 1, (int)n, st));
+    BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, sel_tmp, rpos, d_cand, (int)n, 0, 32, st));
     BS_HIP(ctx, ctx->cub_tmp.reserve(sel_tmp));
   }
   auto commit_plane = [&](const PlaneOut& o, const int32_t* src_pool) -> int {
@@ -1157,17 +1159,20 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     const int npend = (int)pending.size();
     // lowest new plane-attempt candidates under the current owners (pending
     // planes are in the structure, their seeds are not candidates)
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, flags, nullptr);
-    {
-      hipcub::CountingInputIterator<int32_t> it(0);
-      size_t tb = sel_tmp;
-      BS_HIP(ctx, hipcub::DeviceSelect::Flagged(ctx->cub_tmp.p, tb, it, flags, d_cand, d_misc + 1, (int)n, st));
-    }
+    // (one pass: the sparse candidates are appended unordered into rpos -- free after the reverse
+    // lists were built -- and the few entries are sorted; a flag array + stream compaction over
+    // all n points cost 0.7 ms per round at 50 M)
+    BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
+    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, nullptr, rpos, d_misc + 1);
     int32_t ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
     if (ncand_all == 0 && npend == 0)
       break;  // no plane attempt left: omega is the final owner array
+    if (ncand_all > 0) {
+      size_t tb = sel_tmp;
+      BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tb, rpos, d_cand, ncand_all, 0, 32, st));
+    }
     const int ncand = std::min<int>(ncand_all, max_waves);
     if (npend)
       BS_HIP(ctx, hipMemcpyAsync(d_pend, pending.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
@@ -1212,7 +1217,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       validate2_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, omega, d_neigh, K);
     int32_t inf = INF;
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 2, &inf, sizeof inf, hipMemcpyHostToDevice, st));
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, d_misc + 2);
+    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, d_misc + 2, nullptr, nullptr);
     int32_t new_min = INF;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
     if (ncand)
