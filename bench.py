@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- Mpoints/s segmented (kNN + normal + label) on MI355X.
 
-One "step" = one pass of the whole hot path (bs_segment_dev: search grid,
-kNN + PCA normals, region-growing labels) over one device-resident synthetic
-cloud.  N=1 workload: BASELINE.json configs[1], the 1 M-point synthetic
-building facade at k=16 (buildingsegment_amd.synth.facade).
-With --gpus N every rank segments its own facade (independent objects, no
-data-path collective): weak scaling.
+One "step" = one pass of the whole hot path (search grid, kNN + PCA normals,
+region-growing labels) over one device-resident synthetic cloud.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus
-``roofline`` (dominant kernel, HIP-event timed on the launch stream),
-``cpu_baseline`` (the CPU oracle timed on this box's host cores, N=1 only) and
-``secondary`` (configs[2], the 10 M-point urban block at k=32, measured live the
-same way: the multi-plane regime; `--secondary ''` skips it).
+N = 1 (default): the configuration north_star quotes its target on -- the
+50 M-point synthetic building cloud at k=16 on ONE GPU (`urban_50m`, SURVEY.md
+8(d) C3; it fits one MI355X).  `secondary` carries BASELINE.json configs[1]
+(1 M facade, k=16) and configs[2] (10 M urban block, k=32), measured live with
+the same protocol, each with its own `roofline` block.
+
+N > 1 (`--gpus N`, one rank per GPU over RCCL): ONE urban_50m cloud is segmented
+by buildingsegment_amd.dist.segment_sharded_dev -- stages 1-2 sharded by Morton
+slabs with a device-resident halo exchange, stage 3 "replicas only" (rank 0
+grows, labels are broadcast) -- strong scaling, stage times reported separately.
+`python bench.py --gpus N` without a launcher starts the N ranks itself (before
+anything touches the GPU); under torchrun WORLD_SIZE must equal --gpus.
+
+Prints ONE JSON line (rank 0): the driver's contract fields plus `roofline`
+(dominant kernel: algorithmic bytes / HIP-event launch time on the launch stream)
+and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import platform
+import subprocess
 import sys
 import time
 
@@ -28,6 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+WORKLOADS = ["urban_50m", "urban_10m", "facade_1m", "plane_cube_100k", "uniform_1m", "urban_2m", "urban_200m"]
+K_DEFAULT = {"facade_1m": 16, "urban_10m": 32, "urban_50m": 16, "urban_2m": 16, "plane_cube_100k": 15,
+             "uniform_1m": 16, "urban_200m": 16}
 
 
 def parse():
@@ -35,30 +47,44 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="facade_1m", choices=["facade_1m", "urban_10m", "plane_cube_100k",
-                                                                "uniform_1m", "urban_2m", "urban_50m"])
+    ap.add_argument("--workload", default="urban_50m", choices=WORKLOADS)
     ap.add_argument("--k", type=int, default=0, help="neighbour-list length (0 = workload default)")
     ap.add_argument("--rg-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 control "
-                         "flow with several ranks sharing one GPU)")
-    ap.add_argument("--secondary", default="urban_10m",
-                    help="second workload measured live and reported under 'secondary' ('' = none)")
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path "
+                         "with several ranks sharing one GPU)")
+    ap.add_argument("--secondary", default="facade_1m,urban_10m",
+                    help="comma-separated workloads measured live after the headline and reported under "
+                         "'secondary' ('' = none; ignored for N>1)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N>1: every rank segments its own copy of the workload (weak scaling of independent "
+                         "clouds, no data-path collective) instead of sharding one cloud")
     return ap.parse_args()
 
 
-def make_cloud(name: str, rank: int):
-    """The named BASELINE workload.  Every rank segments its own copy of the SAME cloud (the
-    config names one seed): weak scaling then measures the system, not the luck of a seed --
-    the façade's critical chain varies by 40 % between seeds."""
+def make_cloud(name: str, rank: int = 0):
+    """The named BASELINE workload: (xyz int32 [n,3], default k)."""
     from buildingsegment_amd import synth
+    cache = os.environ.get("BS_CLOUD_CACHE")  # developer aid: reuse a generated cloud between processes on one box
+    if cache:
+        f = os.path.join(cache, f"bs_cloud_{name}.npy")
+        if os.path.exists(f):
+            return np.load(f), K_DEFAULT[name]
+        os.environ.pop("BS_CLOUD_CACHE")
+        xyz, k = make_cloud(name, rank)
+        os.environ["BS_CLOUD_CACHE"] = cache
+        np.save(f + ".tmp.npy", xyz)
+        os.replace(f + ".tmp.npy", f)
+        return xyz, k
     if name == "facade_1m":
         return synth.facade(n_side=1000, seed=2), 16
     if name == "urban_10m":
         return synth.urban(10_000_000, seed=3), 32
     if name == "urban_50m":
         return synth.urban(50_000_000, seed=4), 16
+    if name == "urban_200m":
+        return synth.urban(200_000_000, seed=5), 16
     if name == "urban_2m":
         return synth.urban(2_000_000, seed=3), 16
     if name == "plane_cube_100k":
@@ -68,47 +94,161 @@ def make_cloud(name: str, rank: int):
     raise ValueError(name)
 
 
-def cpu_baseline(xyz: np.ndarray, k: int):
-    """CPU oracle (oracle/, single thread) on a bounded sample of the same
-    workload: kNN + normals for the first q points against the full cloud,
-    region growing on the first min(n, 1M)-point prefix cloud of its own."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(name: str, xyz: np.ndarray, k: int):
+    """CPU oracle (oracle/bs_oracle.c, ONE thread) on a bounded sample of the same workload.
+
+    Small workloads run whole.  The urban clouds are generated building by building from
+    counter-based streams, so `synth.urban(m, seed)` IS the first m points (the first
+    buildings) of the larger cloud of the same seed: that sub-scene is segmented end to end
+    (kNN + normals + region grow) -- the same density, plane sizes and k as the full job."""
+    from buildingsegment_amd import synth
     from oracle import oracle as O
     n = len(xyz)
-    # ~0.3 Mpts/s for stage 1-2 on one core: cap the sample at 2 M queries
-    q = min(n, 2_000_000)
-    t0 = time.perf_counter()
-    neigh, normals = O.knn_normals(xyz, k=k, q0=0, q1=q)
-    t1 = time.perf_counter()
-    if q == n:
-        O.region_grow(xyz, normals, neigh)
-        t2 = time.perf_counter()
-        t_total = t2 - t0
-        sample = f"whole workload ({n} points): kNN+normals {t1 - t0:.2f}s, region grow {t2 - t1:.2f}s"
+    sample_n = {"urban_50m": 4_000_000, "urban_200m": 4_000_000, "urban_10m": 2_000_000}.get(name, n)
+    if sample_n < n:
+        seed = {"urban_50m": 4, "urban_200m": 5, "urban_10m": 3}[name]
+        sub = synth.urban(sample_n, seed=seed)
+        what = (f"synth.urban({sample_n}, seed={seed}) = the first {sample_n} points (first buildings) of the {name} "
+                "generator stream, whole path")
     else:
-        # region grow needs the full graph; time it on an independent prefix cloud
-        sub = np.ascontiguousarray(xyz[:q])
-        ng2, nr2 = O.knn_normals(sub, k=k)
-        t2 = time.perf_counter()
-        O.region_grow(sub, nr2, ng2)
-        t3 = time.perf_counter()
-        t_total = (t1 - t0) + (t3 - t2)
-        sample = (f"{q} of {n} queries against the full cloud for kNN+normals ({t1 - t0:.2f}s) + region grow "
-                  f"of a {q}-point prefix cloud ({t3 - t2:.2f}s)")
-    return {"value": q / t_total / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port", "sample": sample}
+        sub = xyz
+        what = f"whole workload ({n} points)"
+    t0 = time.perf_counter()
+    neigh, normals = O.knn_normals(sub, k=k)
+    t1 = time.perf_counter()
+    O.region_grow(sub, normals, neigh)
+    t2 = time.perf_counter()
+    return {"value": len(sub) / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+            "sample": f"{what}: kNN+normals {t1 - t0:.2f}s, region grow {t2 - t1:.2f}s on 1 thread"}
+
+
+def roofline_block(n, k, stage, launches_per_step, rg_mode, workload):
+    """Dominant kernel by time.  Algorithmic bytes per point:
+      kNN+normals: read xyz 12 + write k*4 + write normal 24 (+12: second read of xyz)
+      region grow: read neigh row k*4 + xyz 12 + normal 24 + write label 4
+    One pass of region growing is spread over `launches_per_step` launches of the
+    plane-growth kernel (one per speculative round): bytes per launch = n(4k+40)/rounds,
+    average launch duration from HIP events recorded around each launch on the stream."""
+    lps = max(launches_per_step, 1.0)
+    grow_bytes = n * (4 * k + 40) / lps
+    knn_bytes = n * (4 * k + 36 + 12)
+    grow_avg = stage["grow_kernel_ms"] / lps
+    if stage["grow_kernel_ms"] >= stage["knn_ms"]:
+        dom = "grow_spec_kernel" if rg_mode != 1 else "grow_seq_kernel"
+        dbytes, dms = grow_bytes, grow_avg
+    else:
+        dom, dbytes, dms = "knn_fast_kernel", knn_bytes, stage["knn_ms"]
+    achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel: NOT live (the counters cannot be read from inside the
+    # bench) -- taken from the committed rocprofv3 PMC passes of the same command (tools/pmc_traffic.py)
+    traffic, src = None, None
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        ent = pt.get(workload) if isinstance(pt.get(workload), dict) else (pt if pt.get("workload") == workload else None)
+        if ent and rg_mode != 1:
+            if dom == "grow_spec_kernel":
+                traffic = ent["grow_spec_kernel_bytes_per_call"] / lps
+            else:
+                traffic = ent["knn_fast_kernel_bytes_per_call"]
+            src = "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
+    except (OSError, ValueError, KeyError, TypeError):
+        traffic = None
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "alg_bytes_per_launch": dbytes, "avg_ms": dms, "launches_per_step": lps}
+
+
+def measure_single(ctx, api, torch, dev, name, k_override, rg_mode, steps, warmup, fence, world=1, all_reduce_max=None):
+    """Whole path on one GPU per rank (bs_segment_dev), inputs resident in HBM."""
+    xyz, k = make_cloud(name)
+    if k_override:
+        k = k_override
+    n = len(xyz)
+    params = api.default_params(k=k, rg_mode=rg_mode)
+    d_xyz = torch.from_numpy(xyz).to(dev)
+    d_neigh = torch.empty((n, k), dtype=torch.int32, device=dev)
+    d_normals = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_plane = torch.empty((n,), dtype=torch.int32, device=dev)
+
+    def step():
+        ctx.segment_dev(d_xyz.data_ptr(), n, d_plane.data_ptr(), params, d_neigh.data_ptr(), d_normals.data_ptr())
+
+    for _ in range(warmup):
+        step()
+    fence()
+    stage = {"grid_ms": 0.0, "knn_ms": 0.0, "grow_ms": 0.0, "grow_kernel_ms": 0.0, "grow_setup_ms": 0.0}
+    launches = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        tm = ctx.timings()  # HIP-event stage times of this step (events on the launch stream)
+        for kk in stage:
+            stage[kk] += tm.get(kk, 0.0)
+        launches += tm["grow_kernel_launches"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if all_reduce_max is not None:
+        elapsed = all_reduce_max(elapsed)
+    tm = ctx.timings()
+    for kk in stage:
+        stage[kk] /= max(steps, 1)
+    res = {"workload": name, "points": n, "k": k, "steps": steps, "warmup": warmup,
+           "value": world * n * steps / elapsed / 1e6, "unit": "Mpoints/s", "ms_per_step": elapsed / max(steps, 1) * 1e3,
+           "stages_ms": stage, "rg_rounds": tm["rg_rounds"], "largest_plane": tm["largest_plane"],
+           "seed_attempts": tm["n_seed_attempts"], "fallback_queries": tm["n_fallback_queries"],
+           "end_to_end_alg_GBps": n * (88 + 8 * k) / (elapsed / max(steps, 1)) / 1e9,
+           "roofline": roofline_block(n, k, stage, launches / max(steps, 1), rg_mode, name),
+           "radius_mm": params.radius, "max_nn": params.max_nn}
+    del d_xyz, d_neigh, d_normals, d_plane
+    torch.cuda.empty_cache()
+    return res, xyz, k
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a
+    CHILD process (nothing has touched the GPU yet) and exit with its code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args))
+        world = 1
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled run", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "gloo":  # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks
+        if args.backend == "gloo":  # rehearsal of the N>1 path on a box with fewer GPUs than ranks
             local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
@@ -122,22 +262,9 @@ def main():
 
     from buildingsegment_amd import api
 
-    xyz, k = make_cloud(args.workload, rank)
-    if args.k:
-        k = args.k
-    n = len(xyz)
-    params = api.default_params(k=k, rg_mode=args.rg_mode)
     ctx = api.Context(local_rank)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
-
-    d_xyz = torch.from_numpy(xyz).to(dev)
-    d_neigh = torch.empty((n, k), dtype=torch.int32, device=dev)
-    d_normals = torch.empty((n, 3), dtype=torch.float64, device=dev)
-    d_plane = torch.empty((n,), dtype=torch.int32, device=dev)
-
-    def step():
-        ctx.segment_dev(d_xyz.data_ptr(), n, d_plane.data_ptr(), params, d_neigh.data_ptr(), d_normals.data_ptr())
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -145,118 +272,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    stage = {"grid_ms": 0.0, "knn_ms": 0.0, "grow_ms": 0.0, "grow_kernel_ms": 0.0}
-    launches = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        tm = ctx.timings()  # HIP-event stage times of this step (events on the launch stream)
-        for kk in stage:
-            stage[kk] += tm[kk]
-        launches += tm["grow_kernel_launches"]
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    def all_reduce_max(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tm = ctx.timings()
-    steps = max(args.steps, 1)
-    for kk in stage:
-        stage[kk] /= steps
+        return float(t.item())
 
-    if rank == 0:
-        value = world * n * args.steps / elapsed / 1e6
-        # Dominant kernel by time.  Algorithmic bytes per point:
-        #   kNN+normals: read xyz 12 + write k*4 + write normal 24 (+12: second read of xyz)
-        #   region grow: read neigh row k*4 + xyz 12 + normal 24 + write label 4
-        # One pass of region growing is spread over `launches/steps` launches of the
-        # plane-growth kernel (one per speculative round): bytes per launch = n(4k+40)/rounds,
-        # average launch duration from HIP events recorded around each launch on the stream.
-        lps = max(launches / steps, 1.0)
-        grow_bytes = n * (4 * k + 40) / lps
-        knn_bytes = n * (4 * k + 36 + 12)
-        grow_avg = stage["grow_kernel_ms"] / lps
-        if stage["grow_kernel_ms"] >= stage["knn_ms"]:
-            dom = "grow_spec_kernel" if args.rg_mode != 1 else "grow_seq_kernel"
-            dbytes, dms = grow_bytes, grow_avg
-        else:
-            dom, dbytes, dms = "knn_fast_kernel", knn_bytes, stage["knn_ms"]
-        achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-        # (tools/pmc_traffic.py; the counters cannot be read live from inside the bench)
-        traffic = None
-        try:
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("workload") == args.workload and args.rg_mode != 1:
-                if dom == "grow_spec_kernel":
-                    traffic = pt["grow_spec_kernel_bytes_per_call"] / lps
-                else:
-                    traffic = pt["knn_fast_kernel_bytes_per_call"]
-        except (OSError, ValueError, KeyError, TypeError):
-            traffic = None
-        out = {
-            "metric": "Mpoints/s segmented (kNN+normal+label)",
-            "value": value,
-            "unit": "Mpoints/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int32 coordinates / f64 normals",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "points_per_gpu": n, "k": k, "radius_mm": params.radius,
-                       "max_nn": params.max_nn, "rg_mode": args.rg_mode,
-                       "largest_plane": tm["largest_plane"], "seed_attempts": tm["n_seed_attempts"],
-                       "fallback_queries": tm["n_fallback_queries"], "rg_rounds": tm["rg_rounds"]},
-            "stages_ms": stage,
-            "end_to_end_alg_GBps": n * (88 + 8 * k) / (elapsed / steps) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": dbytes, "avg_ms": dms, "launches_per_step": lps},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(xyz, k)
-    # Secondary workload, measured live with the same barrier/timing protocol: BASELINE.json
-    # configs[2] (10 M-point urban block, k=32) shows the multi-plane regime of stage 3, which
-    # the single-surface facade cannot (its large planes form one dependency chain).
-    if args.secondary and args.secondary != args.workload:
-        del d_xyz, d_neigh, d_normals, d_plane
-        torch.cuda.empty_cache()
-        xyz2, k2 = make_cloud(args.secondary, rank)
-        n2 = len(xyz2)
-        p2 = api.default_params(k=k2, rg_mode=args.rg_mode)
-        e_xyz = torch.from_numpy(xyz2).to(dev)
-        e_neigh = torch.empty((n2, k2), dtype=torch.int32, device=dev)
-        e_normals = torch.empty((n2, 3), dtype=torch.float64, device=dev)
-        e_plane = torch.empty((n2,), dtype=torch.int32, device=dev)
-
-        def step2():
-            ctx.segment_dev(e_xyz.data_ptr(), n2, e_plane.data_ptr(), p2, e_neigh.data_ptr(), e_normals.data_ptr())
-
-        step2()
+    common = {"metric": "Mpoints/s segmented (kNN+normal+label)", "unit": "Mpoints/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+              "dtype": "int32 coordinates / f64 normals", "data": "synthetic"}
+    out = None
+    if world == 1 or args.replicas:
+        res, xyz, k = measure_single(ctx, api, torch, dev, args.workload, args.k, args.rg_mode, args.steps, args.warmup,
+                                     fence, world, all_reduce_max if world > 1 else None)
+        if rank == 0:
+            out = dict(common)
+            out.update({"value": res["value"], "ms_per_step": res["ms_per_step"], "scaling": "weak",
+                        "config": {"workload": args.workload, "points_per_gpu": res["points"], "k": res["k"],
+                                   "radius_mm": res["radius_mm"], "max_nn": res["max_nn"], "rg_mode": args.rg_mode,
+                                   "largest_plane": res["largest_plane"], "seed_attempts": res["seed_attempts"],
+                                   "fallback_queries": res["fallback_queries"], "rg_rounds": res["rg_rounds"],
+                                   "parallelism": "1 GPU, whole path" if world == 1 else f"{world} independent replicas"},
+                        "stages_ms": res["stages_ms"], "end_to_end_alg_GBps": res["end_to_end_alg_GBps"],
+                        "roofline": res["roofline"]})
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.workload, xyz, k)
+        del xyz
+        if world == 1 and args.secondary:
+            sec = []
+            for name in [s for s in args.secondary.split(",") if s and s != args.workload]:
+                r2, _, _ = measure_single(ctx, api, torch, dev, name, 0, args.rg_mode, 2, 1, fence)
+                for drop in ("radius_mm", "max_nn"):
+                    r2.pop(drop)
+                sec.append(r2)
+            if rank == 0 and sec:
+                out["secondary"] = sec
+    else:
+        # ONE cloud sharded over the ranks (north_star: Morton slabs + halo exchange); stage 3 replicas only
+        from buildingsegment_amd import dist as bsd
+        xyz, k = make_cloud(args.workload)
+        if args.k:
+            k = args.k
+        n = len(xyz)
+        params = api.default_params(k=k, rg_mode=args.rg_mode)
+        b = bsd.slab_bounds(n, world)
+        # resident input: rank r holds the r-th 1/N of the cloud in INPUT order (+ the global indices);
+        # the Morton partition, the halo exchange and every gather are inside the timed region
+        d_own = torch.from_numpy(xyz[b[rank]:b[rank + 1]]).to(dev)
+        d_gidx = torch.arange(b[rank], b[rank + 1], dtype=torch.int32, device=dev)
+        del xyz
+        st = {"partition_ms": 0.0, "halo_ms": 0.0, "knn_normals_ms": 0.0, "gather_ms": 0.0, "grow_ms": 0.0}
+        info = {}
+        for _ in range(args.warmup):
+            bsd.segment_sharded_dev(ctx, d_own, d_gidx, n, params)
         fence()
         t0 = time.perf_counter()
-        for _ in range(2):
-            step2()
+        for _ in range(args.steps):
+            _, info = bsd.segment_sharded_dev(ctx, d_own, d_gidx, n, params)
+            for kk in st:
+                st[kk] += info["stage_ms"][kk]
         fence()
-        el2 = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el2], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        tm2 = ctx.timings()
+        elapsed = all_reduce_max(time.perf_counter() - t0)
+        for kk in st:
+            st[kk] = all_reduce_max(st[kk] / max(args.steps, 1))
         if rank == 0:
-            out["secondary"] = {"workload": args.secondary, "points_per_gpu": n2, "k": k2, "steps": 2, "warmup": 1,
-                                "value": world * n2 * 2 / el2 / 1e6, "unit": "Mpoints/s", "ms_per_step": el2 / 2 * 1e3,
-                                "grid_ms": tm2["grid_ms"], "knn_ms": tm2["knn_ms"], "grow_ms": tm2["grow_ms"],
-                                "rg_rounds": tm2["rg_rounds"], "largest_plane": tm2["largest_plane"]}
+            out = dict(common)
+            out.update({"value": n * args.steps / elapsed / 1e6, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+                        "scaling": "strong",
+                        "config": {"workload": args.workload, "points_total": n, "k": k, "rg_mode": args.rg_mode,
+                                   "parallelism": f"stages 1-2: {world} Morton slabs + device halo all-gather (RCCL); "
+                                                  "stage 3: replicas only (rank 0 grows, labels broadcast)",
+                                   "halo_mm": info.get("halo"), "halo_retries": info.get("retries"),
+                                   "n_local_rank0": info.get("n_local")},
+                        "stages_ms": st,
+                        "stage12_Mpoints_per_s": n / ((st["partition_ms"] + st["halo_ms"] + st["knn_normals_ms"]) * 1e-3) / 1e6,
+                        "roofline": None})
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,13 +1,15 @@
-"""N>1 path on CPU: world_size-2 gloo run of buildingsegment_amd.dist with the
-CPU oracle injected as compute backend (the HIP backend needs a GPU; the
-orchestration -- Morton slabs, halo all-gather, certification + retry, graph
-all-gather, rank-0 region grow, label broadcast -- is identical)."""
+"""N>1 path on CPU: world_size-2/3 gloo runs of buildingsegment_amd.dist.segment_sharded_dev
+with the CPU oracle injected as compute backend (the HIP backend needs a GPU).  The
+orchestration under test is the SAME code bench.py --gpus N runs on device tensors: Morton
+partition (all-to-all), voxel halo (all-to-all), certification + retry, graph to rank 0,
+rank-0 region grow, label broadcast."""
 import os
 import socket
 import sys
 
 import numpy as np
 import pytest
+import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -15,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleBackend:
-    """Slab semantics of bs_knn_normals_halo restated with the CPU oracle:
+    """Slab semantics of bs_knn_normals_dev(d_gidx, cert_radius) restated with the CPU oracle:
     ties by GLOBAL index (local cloud sorted by gidx first), global indices out,
     certification = k-th distance < cert_radius."""
 
@@ -23,7 +25,8 @@ class OracleBackend:
         from oracle import oracle as O
         self.O = O
 
-    def knn_normals_halo(self, xyz_local, gidx, n_query, params, cert_radius):
+    def knn_normals(self, xyz_loc, gidx_loc, n_query, params, cert_radius):
+        xyz_local, gidx = xyz_loc.numpy(), gidx_loc.numpy()
         order = np.argsort(gidx, kind="stable")
         rank_of = np.empty(len(order), np.int64)
         rank_of[order] = np.arange(len(order))
@@ -31,14 +34,16 @@ class OracleBackend:
         ng, nr = self.O.knn_normals(xs, k=params.k, radius=params.radius, max_nn=params.max_nn)
         q = rank_of[:n_query]
         ngq, nrq = ng[q], nr[q]
-        d = xs[ngq[:, -1]].astype(np.int64) - xs[q].astype(np.int64)
-        unc = int(((d * d).sum(1) >= cert_radius * cert_radius).sum())
-        return gs[ngq].astype(np.int32), nrq, unc
+        unc = 0
+        if cert_radius > 0:
+            d = xs[ngq[:, -1]].astype(np.int64) - xs[q].astype(np.int64)
+            unc = int(((d * d).sum(1) >= cert_radius * cert_radius).sum())
+        return torch.from_numpy(gs[ngq].astype(np.int32)), torch.from_numpy(nrq), unc
 
     def region_grow(self, xyz, normals, neigh, params):
-        pi, pl = self.O.region_grow(xyz, normals, neigh, th_thickness=params.th_thickness,
+        pi, pl = self.O.region_grow(xyz.numpy(), normals.numpy(), neigh.numpy(), th_thickness=params.th_thickness,
                                     th_point_count=params.th_point_count, cos_th=params.cos_th)
-        return pi, pl
+        return torch.from_numpy(pi), pl
 
 
 def _free_port():
@@ -49,42 +54,65 @@ def _free_port():
     return p
 
 
+def _params(k=15):
+    from buildingsegment_amd import _lib
+    return _lib.Params(k=k, max_nn=50, radius=100.0, th_thickness=300, th_point_count=400, cos_th=0.88,
+                       cell_size=0, rg_mode=0)
+
+
 def _worker(rank, world, port, halo, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from buildingsegment_amd import _lib, dist as bsd, synth
-    p = _lib.Params(k=15, max_nn=50, radius=100.0, th_thickness=300, th_point_count=400, cos_th=0.88,
-                    cell_size=0, rg_mode=0)
+    from buildingsegment_amd import dist as bsd, synth
     xyz = synth.plane_cube()[:24000].copy()
-    own_xyz, own_idx = bsd.partition_morton(xyz, world, rank)
-    ng, nr, labels, planes, info = bsd.segment_sharded(own_xyz, own_idx, len(xyz), OracleBackend(), p, halo=halo)
-    np.savez(out % rank, idx=own_idx, ng=ng, nr=nr, labels=labels, retries=info["retries"], n_local=info["n_local"])
+    n = len(xyz)
+    b = bsd.slab_bounds(n, world)  # the input split is arbitrary: a contiguous 1/N of the input order
+    d_xyz = torch.from_numpy(xyz[b[rank]:b[rank + 1]])
+    d_gidx = torch.arange(b[rank], b[rank + 1], dtype=torch.int32)
+    labels, info = bsd.segment_sharded_dev(OracleBackend(), d_xyz, d_gidx, n, _params(), halo=halo)
+    np.savez(out % rank, idx=info["gidx_own"].numpy(), ng=info["neigh_own"].numpy(), nr=info["normals_own"].numpy(),
+             labels=labels.numpy(), retries=info["retries"], n_local=info["n_local"],
+             nplanes=-1 if info["planes"] is None else len(info["planes"]["id"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("halo", [250.0, 30.0])
-def test_two_rank_slab_run_equals_single_process(oracle, tmp_path, halo):
+@pytest.mark.parametrize("world,halo", [(2, 250.0), (2, 30.0), (3, 200.0)])
+def test_sharded_run_equals_single_process(oracle, tmp_path, world, halo):
     from buildingsegment_amd import synth
-    world = 2
     out = str(tmp_path / "r%d.npz")
     mp.spawn(_worker, args=(world, _free_port(), halo, out), nprocs=world, join=True)
     xyz = synth.plane_cube()[:24000].copy()
     ng, nr = oracle.knn_normals(xyz, k=15)
-    pi, _ = oracle.region_grow(xyz, nr, ng)
-    seen = np.zeros(len(xyz), bool)
+    pi, pl = oracle.region_grow(xyz, nr, ng)
+    seen = np.zeros(len(xyz), int)
+    sizes = []
     for r in range(world):
         g = np.load(out % r)
         assert np.array_equal(g["ng"], ng[g["idx"]])      # neighbour indices bit-exact
         assert np.array_equal(g["nr"], nr[g["idx"]])      # normals bit-exact
         assert np.array_equal(g["labels"], pi)            # labels identical on every rank
         assert g["n_local"] < len(xyz)                    # a slab + halo, not the whole cloud
-        seen[g["idx"]] = True
+        assert g["nplanes"] == (len(pl["id"]) if r == 0 else -1)  # stage 3: replicas only, planes on rank 0
+        seen[g["idx"]] += 1
+        sizes.append(len(g["idx"]))
         if halo < 100:
             assert g["retries"] >= 1                      # halo below the hybrid radius is widened
-    assert seen.all()
+    assert (seen == 1).all()                              # the Morton slabs partition the cloud
+    assert max(sizes) < 1.25 * len(xyz) / world           # ... into nearly equal counts
+
+
+def test_single_process_path_without_process_group(oracle):
+    """world 1 (no process group): the same function degenerates to the plain pipeline."""
+    from buildingsegment_amd import dist as bsd, synth
+    xyz = synth.plane_cube()[:9000].copy()
+    labels, info = bsd.segment_sharded_dev(OracleBackend(), torch.from_numpy(xyz), torch.arange(len(xyz), dtype=torch.int32),
+                                           len(xyz), _params())
+    ng, nr = oracle.knn_normals(xyz, k=15)
+    pi, _ = oracle.region_grow(xyz, nr, ng)
+    assert np.array_equal(info["neigh_own"].numpy(), ng) and np.array_equal(labels.numpy(), pi)
 
 
 def test_morton_partition_is_a_partition():

@@ -1,12 +1,15 @@
-"""Sharded single-cloud path with the HIP backend: two processes (gloo for the
-collectives, both computing on cuda:0 through the C ABI) must reproduce the
-single-process oracle results exactly."""
+"""Sharded single-cloud path with the HIP backend: two processes (gloo for the collectives --
+one GPU cannot host two RCCL ranks -- both computing on cuda:0 through the C ABI with DEVICE
+tensors) must reproduce the single-process oracle results exactly.  This is the code path of
+`bench.py --gpus N` (buildingsegment_amd.dist.segment_sharded_dev); with nccl the only
+difference is that `_coll` hands the device tensors to RCCL instead of staging them."""
 import os
 import socket
 import sys
 
 import numpy as np
 import pytest
+import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -27,14 +30,22 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)  # torch initialises the GPU before the HIP library is loaded (as bench.py does)
     from buildingsegment_amd import api, dist as bsd, synth
     ctx = api.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     p = api.default_params(k=16)
     xyz = synth.urban(60_000, seed=12)
-    own_xyz, own_idx = bsd.partition_morton(xyz, world, rank)
-    ng, nr, labels, planes, info = bsd.segment_sharded(own_xyz, own_idx, len(xyz), ctx, p, halo=250.0)
-    np.savez(out % rank, idx=own_idx, ng=ng, nr=nr, labels=labels, n_local=info["n_local"],
-             nplanes=-1 if planes is None else len(planes))
+    n = len(xyz)
+    b = bsd.slab_bounds(n, world)
+    d_xyz = torch.from_numpy(xyz[b[rank]:b[rank + 1]]).to(dev)
+    d_gidx = torch.arange(b[rank], b[rank + 1], dtype=torch.int32, device=dev)
+    labels, info = bsd.segment_sharded_dev(ctx, d_xyz, d_gidx, n, p, halo=250.0)
+    assert labels.is_cuda and info["neigh_own"].is_cuda
+    np.savez(out % rank, idx=info["gidx_own"].cpu().numpy(), ng=info["neigh_own"].cpu().numpy(),
+             nr=info["normals_own"].cpu().numpy(), labels=labels.cpu().numpy(), n_local=info["n_local"],
+             nplanes=-1 if info["planes"] is None else len(info["planes"]))
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
@@ -48,11 +59,13 @@ def test_two_process_sharded_run_on_one_gpu(oracle, tmp_path):
     xyz = synth.urban(60_000, seed=12)
     ng, nr = oracle.knn_normals(xyz, k=16)
     pi, pl = oracle.region_grow(xyz, nr, ng)
+    seen = np.zeros(len(xyz), int)
     for r in range(world):
         g = np.load(out % r)
         assert np.array_equal(g["ng"], ng[g["idx"]])
         assert np.array_equal(g["nr"], nr[g["idx"]])
         assert np.array_equal(g["labels"], pi)
         assert g["n_local"] < len(xyz)
-        if r == 0:
-            assert g["nplanes"] == len(pl["id"])
+        assert g["nplanes"] == (len(pl["id"]) if r == 0 else -1)
+        seen[g["idx"]] += 1
+    assert (seen == 1).all()
