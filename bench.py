@@ -114,7 +114,7 @@ def cpu_baseline(name: str, xyz: np.ndarray, k: int):
     from buildingsegment_amd import synth
     from oracle import oracle as O
     n = len(xyz)
-    sample_n = {"urban_50m": 4_000_000, "urban_200m": 4_000_000, "urban_10m": 2_000_000}.get(name, n)
+    sample_n = {"urban_50m": 2_000_000, "urban_200m": 2_000_000, "urban_10m": 1_000_000}.get(name, n)
     if sample_n < n:
         seed = {"urban_50m": 4, "urban_200m": 5, "urban_10m": 3}[name]
         sub = synth.urban(sample_n, seed=seed)

@@ -40,7 +40,7 @@ class Timings(C.Structure):
     _fields_ = [("grid_ms", C.c_double), ("knn_ms", C.c_double), ("grow_ms", C.c_double),
                 ("total_ms", C.c_double), ("largest_plane", C.c_int64), ("n_seed_attempts", C.c_int64),
                 ("n_fallback_queries", C.c_int64), ("rg_rounds", C.c_int64), ("grow_kernel_ms", C.c_double),
-                ("grow_kernel_launches", C.c_int64)]
+                ("grow_kernel_launches", C.c_int64), ("grow_setup_ms", C.c_double)]
 
 
 class BsError(RuntimeError):

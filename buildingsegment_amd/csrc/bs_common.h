@@ -113,7 +113,7 @@ struct bs_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   bs_timings tm{};
-  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
   // grid scratch
   bs::DevBuf keys_in, keys_out, vals_in, vals_out, cub_tmp, uniq_keys, uniq_cnt, misc;
@@ -123,7 +123,7 @@ struct bs_ctx {
   // pipeline scratch (bs_segment_dev with NULL outputs)
   bs::DevBuf seg_neigh, seg_normals;
   // region-grow state
-  bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec, rg_radj;
+  bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec, rg_radj, rg_roff;
   int64_t rg_n = 0;
   bool rg_valid = false;
   // 2-D raster scratch (bs_raster.hip)

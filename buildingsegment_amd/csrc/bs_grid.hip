@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 #include "bs_common.h"
 
@@ -60,8 +61,35 @@ __global__ void bbox_kernel(const int32_t* __restrict__ xyz, int64_t n, int32_t*
   }
 }
 
+// Sort key of a cell.  The hash table is keyed by pack_cell(); the ORDER of the cells in
+// the sorted copy is free (only "points of one cell are contiguous" matters).  Morton
+// (Z-curve) order keeps cells that are adjacent in ANY axis close in memory, so the
+// gathers of everything that walks the cell-sorted order (kNN candidates, static masks,
+// reverse lists, owner passes) find their neighbours' lines in the XCD's L2; the raster
+// order (x fastest) separates y/z neighbours by a whole row / layer of the scene.
+__host__ __device__ inline uint64_t spread21(uint64_t v)
+{
+  v &= 0x1FFFFFull;
+  v = (v | (v << 32)) & 0x1F00000000FFFFull;
+  v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+__host__ __device__ inline uint32_t compact21(uint64_t v)
+{
+  v &= 0x1249249249249249ull;
+  v = (v | (v >> 2)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v >> 4)) & 0x100F00F00F00F00Full;
+  v = (v | (v >> 8)) & 0x1F0000FF0000FFull;
+  v = (v | (v >> 16)) & 0x1F00000000FFFFull;
+  v = (v | (v >> 32)) & 0x1FFFFFull;
+  return (uint32_t)v;
+}
+
 __global__ void cellkey_kernel(const int32_t* __restrict__ xyz, int64_t n, int mnx, int mny, int mnz,
-                               int cell, uint64_t* __restrict__ keys, int32_t* __restrict__ vals)
+                               int cell, int morton, uint64_t* __restrict__ keys, int32_t* __restrict__ vals)
 {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n)
@@ -69,7 +97,7 @@ __global__ void cellkey_kernel(const int32_t* __restrict__ xyz, int64_t n, int m
   uint32_t cx = (uint32_t)(xyz[3 * i] - mnx) / (uint32_t)cell;
   uint32_t cy = (uint32_t)(xyz[3 * i + 1] - mny) / (uint32_t)cell;
   uint32_t cz = (uint32_t)(xyz[3 * i + 2] - mnz) / (uint32_t)cell;
-  keys[i] = pack_cell(cx, cy, cz);
+  keys[i] = morton ? (spread21(cx) | (spread21(cy) << 1) | (spread21(cz) << 2)) : pack_cell(cx, cy, cz);
   if (vals)
     vals[i] = (int32_t)i;
 }
@@ -105,13 +133,15 @@ __global__ void table_clear_kernel(CellEntry* t, uint32_t size)
 }
 
 __global__ void table_insert_kernel(const uint64_t* __restrict__ ukeys, const int32_t* __restrict__ ucnt,
-                                    const int32_t* __restrict__ ustart, int32_t ncell, CellEntry* table,
-                                    uint32_t hmask)
+                                    const int32_t* __restrict__ ustart, int32_t ncell, int morton,
+                                    CellEntry* table, uint32_t hmask)
 {
   int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncell)
     return;
   uint64_t k = ukeys[c];
+  if (morton)
+    k = pack_cell(compact21(k), compact21(k >> 1), compact21(k >> 2));
   uint32_t h = hash_cell(k) & hmask;
   for (;;) {
     unsigned long long prev =
@@ -150,7 +180,7 @@ static int count_cells(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const int m
   hipStream_t st = ctx->stream;
   uint64_t* kin = ctx->keys_in.as<uint64_t>();
   uint64_t* kout = ctx->keys_out.as<uint64_t>();
-  cellkey_kernel<<<grid_blocks(n, 256), 256, 0, st>>>(d_xyz, n, mn[0], mn[1], mn[2], cell, kin, nullptr);
+  cellkey_kernel<<<grid_blocks(n, 256), 256, 0, st>>>(d_xyz, n, mn[0], mn[1], mn[2], cell, 0, kin, nullptr);
   size_t tb = 0;
   BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, kin, kout, (int)n, 0, 63, st));
   BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
@@ -225,7 +255,11 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
   uint64_t* kout = ctx->keys_out.as<uint64_t>();
   int32_t* vin = ctx->vals_in.as<int32_t>();
   int32_t* vout = ctx->vals_out.as<int32_t>();
-  cellkey_kernel<<<grid_blocks(n, 256), 256, 0, st>>>(d_xyz, n, bb[0], bb[1], bb[2], cell, kin, vin);
+  static const int morton = []() {
+    const char* e = getenv("BS_GRID_ORDER");  // developer A/B switch: "raster" restores the x-fastest cell order
+    return (e && e[0] == 'r') ? 0 : 1;
+  }();
+  cellkey_kernel<<<grid_blocks(n, 256), 256, 0, st>>>(d_xyz, n, bb[0], bb[1], bb[2], cell, morton, kin, vin);
   size_t tb = 0;
   BS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, kout, vin, vout, (int)n, 0, 63, st));
   BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
@@ -259,7 +293,7 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
   BS_HIP(ctx, ctx->table.reserve(sizeof(CellEntry) * (size_t)hs));
   CellEntry* table = ctx->table.as<CellEntry>();
   table_clear_kernel<<<(hs + 255) / 256, 256, 0, st>>>(table, hs);
-  table_insert_kernel<<<(nruns + 255) / 256, 256, 0, st>>>(ukeys, ucnt, ustart, nruns, table, hs - 1);
+  table_insert_kernel<<<(nruns + 255) / 256, 256, 0, st>>>(ukeys, ucnt, ustart, nruns, morton, table, hs - 1);
 
   // 6. cell-sorted point copy
   BS_HIP(ctx, ctx->spts.reserve(sizeof(int4) * n));

@@ -277,6 +277,7 @@ int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_no
     if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess)
       ctx->tm.grow_kernel_ms = ms;
     ctx->tm.grow_kernel_launches = 1;
+    ctx->tm.grow_setup_ms = 0.0;
   }
   return BS_OK;
 }

@@ -157,7 +157,7 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
 // order), so that the neighbour gathers of adjacent threads share cache lines.
 // Neighbour geometry comes from the one-line-per-point records.
 __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order, const int4* __restrict__ rec,
-                                   int quads, uint32_t* __restrict__ hmask)
+                                   int quads, uint32_t* __restrict__ hmask, int32_t* __restrict__ rcnt)
 {
   const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
   if (s >= a.n)
@@ -179,8 +179,10 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
     const double dist = __builtin_fabs((double)dx * cnx + (double)dy * cny + (double)dz * cnz);
     const double dt = cnx * __hiloint2double(q1.y, q1.x) + cny * __hiloint2double(q1.w, q1.z) +
                       cnz * __hiloint2double(q2.y, q2.x);
-    if (dist <= a.th && dt >= a.cos_th)
+    if (dist <= a.th && dt >= a.cos_th) {
       m |= 1u << (t - 1);
+      atomicAdd(&rcnt[row[t]], 1);  // |R(c)|: the reverse lists are counted in the same pass
+    }
   }
   hmask[i] = m;
 }
@@ -193,24 +195,8 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
 // points until nothing flips.  Dependencies only run from lower to higher
 // indices, so the iteration settles bottom-up to the unique fixed point; work is
 // proportional to what actually changes, not to n.
-__global__ void rev_count_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                 int64_t n, const int32_t* __restrict__ order, int32_t* __restrict__ rcnt)
-{
-  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
-  if (s >= n)
-    return;
-  const int64_t i = order ? order[s] : s;
-  uint32_t m = hmask[i];
-  const int32_t* row = neigh + i * K;
-  while (m) {
-    const int t = __ffs(m) - 1;
-    m &= m - 1;
-    atomicAdd(&rcnt[row[t + 1]], 1);
-  }
-}
-
 __global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                int64_t n, const int32_t* __restrict__ order, const int32_t* __restrict__ roff,
+                                int64_t n, const int32_t* __restrict__ order, const int64_t* __restrict__ roff,
                                 int32_t* __restrict__ rpos, int32_t* __restrict__ radj)
 {
   const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
@@ -227,56 +213,71 @@ __global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_
   }
 }
 
-__global__ void pull_pass_kernel(int64_t n, int K, const uint32_t* __restrict__ hmask,
+__global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __restrict__ hmask,
                                  const int32_t* __restrict__ neigh, const uint8_t* __restrict__ ps,
-                                 const int32_t* __restrict__ base, const int32_t* __restrict__ roff,
+                                 const int32_t* __restrict__ base, const int64_t* __restrict__ roff,
                                  const int32_t* __restrict__ radj, int32_t* __restrict__ omega, uint8_t* occ,
                                  uint8_t* dirty_cur, uint8_t* dirty_next, uint8_t* bdirty_cur, uint8_t* bdirty_next,
                                  int4* rec, int quads, int* any)
 {
-  // block-level dirty flag (one per 256 points): late passes touch a few points of a
-  // 50 M cloud, and a pass that reads every point's flag costs 0.18 ms of pure scan
-  __shared__ int block_dirty;
-  if (threadIdx.x == 0) {
-    block_dirty = bdirty_cur[blockIdx.x];
-    bdirty_cur[blockIdx.x] = 0;
+  // Dirty flags on two levels: one per point and one per 256 points.  A workgroup owns `sub`
+  // (<= 64) consecutive 256-point groups and visits only the dirty ones: late passes touch a few
+  // points of a 50 M cloud, and one workgroup per 256 points cost 0.19 ms per pass in block
+  // launches alone (260 passes per segmentation).
+  __shared__ unsigned long long sub_mask;
+  const int64_t nb256 = (n + 255) >> 8;
+  const int64_t g0 = (int64_t)blockIdx.x * sub;
+  if (threadIdx.x < 64) {
+    const int64_t gidx = g0 + threadIdx.x;
+    const bool d = (int)threadIdx.x < sub && gidx < nb256 && bdirty_cur[gidx] != 0;
+    if (d)
+      bdirty_cur[gidx] = 0;
+    const unsigned long long m = ballot64(d);
+    if (threadIdx.x == 0)
+      sub_mask = m;
   }
   __syncthreads();
-  if (!block_dirty)
-    return;
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= n || !dirty_cur[c])
-    return;
-  dirty_cur[c] = 0;
-  int32_t v = base[c];
-  const int32_t e1 = roff[c + 1];
-  for (int32_t e = roff[c]; e < e1; e++) {
-    const int32_t j = radj[e];
-    if (j < v && __hip_atomic_load(occ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      v = j;
-  }
-  omega[c] = v;
-  reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;  // the growth kernel reads the owner from the record
-  const uint32_t m0 = hmask[c];
-  const uint8_t want = (m0 != 0 && !ps[c] && v >= (int32_t)c) ? 1 : 0;
-  if (want != occ[c]) {
-    __hip_atomic_store(occ + c, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int32_t* row = neigh + c * K;
-    uint32_t m = m0;
-    while (m) {
-      const int t = __ffs(m) - 1;
-      m &= m - 1;
-      const int32_t q = row[t + 1];
-      dirty_next[q] = 1;
-      bdirty_next[q >> 8] = 1;
+  unsigned long long gm = sub_mask;
+  bool flipped = false;
+  while (gm) {
+    const int t = __ffsll(gm) - 1;
+    gm &= gm - 1;
+    const int64_t c = ((g0 + t) << 8) + threadIdx.x;
+    if (c >= n || !dirty_cur[c])
+      continue;
+    dirty_cur[c] = 0;
+    int32_t v = base[c];
+    const int64_t e1 = roff[c + 1];
+    for (int64_t e = roff[c]; e < e1; e++) {
+      const int32_t j = radj[e];
+      if (j < v && __hip_atomic_load(occ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        v = j;
     }
-    *any = 1;
+    omega[c] = v;
+    reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;  // the growth kernel reads the owner from the record
+    const uint32_t m0 = hmask[c];
+    const uint8_t want = (m0 != 0 && !ps[c] && v >= (int32_t)c) ? 1 : 0;
+    if (want != occ[c]) {
+      __hip_atomic_store(occ + c, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t* row = neigh + c * K;
+      uint32_t m = m0;
+      while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        const int32_t q = row[b + 1];
+        dirty_next[q] = 1;
+        bdirty_next[q >> 8] = 1;
+      }
+      flipped = true;
+    }
   }
+  if (flipped)
+    *any = 1;
 }
 
 // BS_VERIFY=1: is (omega, occ) a fixed point of the owner equations?
 __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ hmask, const uint8_t* __restrict__ ps,
-                                       const int32_t* __restrict__ base, const int32_t* __restrict__ roff,
+                                       const int32_t* __restrict__ base, const int64_t* __restrict__ roff,
                                        const int32_t* __restrict__ radj, const int32_t* __restrict__ omega,
                                        const uint8_t* __restrict__ occ, int* nbad)
 {
@@ -284,7 +285,7 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
   if (c >= n)
     return;
   int32_t v = base[c];
-  for (int32_t e = roff[c]; e < roff[c + 1]; e++) {
+  for (int64_t e = roff[c]; e < roff[c + 1]; e++) {
     const int32_t j = radj[e];
     const bool oj = hmask[j] != 0 && !ps[j] && omega[j] >= j;
     if (oj && j < v)
@@ -951,6 +952,10 @@ __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
 
 inline int nblk(int64_t n, int b) { return (int)((n + b - 1) / b); }
 
+struct ToI64 {
+  __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
+};
+
 }  // namespace
 
 int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
@@ -959,8 +964,6 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   hipStream_t st = ctx->stream;
   ctx->rg_valid = false;
   const int K = p.k;
-  if (n * (int64_t)(K - 1) >= (int64_t)INT32_MAX)
-    return fail(ctx, BS_ERR_INVALID, "n * (k - 1) must fit in int32 (reverse edge list)");
   const int64_t list_cap = 2 * n + 64;
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;
   // round pool: lists + stacks + logs of every concurrent attempt
@@ -987,7 +990,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
                            sizeof(PlaneOut) * (MAX_WAVES + MAX_PENDING) + sizeof(CopyDesc) * (MAX_WAVES + MAX_PENDING);
   BS_HIP(ctx, ctx->rg_aux.reserve(aux_bytes));
   BS_HIP(ctx, ctx->rg_stack.reserve(sizeof(int32_t) * pool_cap));
+  // reverse lists: <= n (k - 1) entries with 64-bit offsets (200 M points at k = 16 are 3.0e9 entries)
   BS_HIP(ctx, ctx->rg_radj.reserve(sizeof(int32_t) * (size_t)(n * (K - 1) + 16)));
+  BS_HIP(ctx, ctx->rg_roff.reserve(sizeof(int64_t) * (size_t)(n + 2)));
+  int64_t* roff = ctx->rg_roff.as<int64_t>();
   int32_t* aux = ctx->rg_aux.as<int32_t>();
   int32_t* d_misc = aux;  // [0]=any [1]=ncand [2]=min_idx ; [16..17] pool top (u64)
   uint32_t* hmask = (uint32_t*)(aux + 1024);
@@ -995,8 +1001,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int32_t* base = aux + 1024 + 2 * n;
   int32_t* dead = aux + 1024 + 3 * n;
   int32_t* d_cand = aux + 1024 + 4 * n;  // select output (n entries)
-  int32_t* roff = aux + 1024 + 5 * n;    // n + 1 (+ pad)
-  int32_t* rpos = aux + 1024 + 6 * n + 64;
+  int32_t* rpos = aux + 1024 + 5 * n;    // n + 1 (+ pad): reverse-list counts / fill cursors, later the candidate scratch
   int32_t* d_seeds = aux + 1024 + 7 * n + 64;  // committed seeds (planes_cap)
   uint8_t* flags = (uint8_t*)(aux + n_i32);
   uint8_t* ps = flags + n;
@@ -1033,22 +1038,17 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   else
     build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec);
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
-  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, order, rec, quads, hmask);
-  // reverse lists of the static masks
-  BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
-  rev_count_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, d_neigh, K, n, order, rpos);
+  // static masks + reverse-list counts in one pass, offsets by a 64-bit exclusive scan over n + 1
+  // entries (roff[n] = total), then the fill
+  (void)hipEventRecord(ctx->ev[8], st);
+  BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));
+  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, order, rec, quads, hmask, rpos);
   {
+    hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*> in(rpos, ToI64());
     size_t tb = 0;
-    BS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rpos, roff, (int)n, st));
+    BS_HIP(ctx, hipcub::DeviceScan::ExclusiveScan(nullptr, tb, in, roff, hipcub::Sum(), (int64_t)0, (int)(n + 1), st));
     BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
-    BS_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tb, rpos, roff, (int)n, st));
-    // roff[n] = roff[n-1] + rcnt[n-1]
-    int32_t last_off = 0, last_cnt = 0;
-    BS_HIP(ctx, hipMemcpyAsync(&last_off, roff + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    BS_HIP(ctx, hipMemcpyAsync(&last_cnt, rpos + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    BS_HIP(ctx, hipStreamSynchronize(st));
-    const int32_t total = last_off + last_cnt;
-    BS_HIP(ctx, hipMemcpyAsync(roff + n, &total, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    BS_HIP(ctx, hipcub::DeviceScan::ExclusiveScan(ctx->cub_tmp.p, tb, in, roff, hipcub::Sum(), (int64_t)0, (int)(n + 1), st));
   }
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
   rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, d_neigh, K, n, order, roff, rpos, radj);
@@ -1066,11 +1066,15 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   uint8_t* bcur = bdirty0;
   uint8_t* bnext = bdirty1;
   int64_t passes = 0;
+  // 256-point groups per workgroup of a pull pass: enough workgroups to fill the chip in the heavy first
+  // passes, few enough that an (almost) idle pass costs microseconds
+  const int pull_sub = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)nb256 / 4096));
   auto propagate = [&]() -> int {
     for (int it = 0; it < 1000000; it++) {
       BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
-      pull_pass_kernel<<<nblk(n, 256), 256, 0, st>>>(n, K, hmask, d_neigh, ps, base, roff, radj, omega, occ, dcur,
-                                                     dnext, bcur, bnext, rec, quads, d_misc);
+      pull_pass_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(n, K, pull_sub, hmask, d_neigh, ps, base, roff, radj,
+                                                                                omega, occ, dcur, dnext, bcur, bnext, rec, quads,
+                                                                                d_misc);
       int any = 0;
       BS_HIP(ctx, hipMemcpyAsync(&any, d_misc, sizeof any, hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
@@ -1095,6 +1099,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int rc = propagate();
   if (rc != BS_OK)
     return rc;
+  (void)hipEventRecord(ctx->ev[9], st);
 
   // persistent store for planes that finished consistently but cannot be
   // finalised yet (an earlier attempt is still open): kept across rounds and
@@ -1153,6 +1158,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     copies.clear();
     return BS_OK;
   };
+  bool cand_listed = false;
+  int32_t ncand_all = 0;
   for (;;) {
     rounds++;
     a.F = F;
@@ -1162,11 +1169,15 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // (one pass: the sparse candidates are appended unordered into rpos -- free after the reverse
     // lists were built -- and the few entries are sorted; a flag array + stream compaction over
     // all n points cost 0.7 ms per round at 50 M)
-    BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, nullptr, rpos, d_misc + 1);
-    int32_t ncand_all = 0;
-    BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    BS_HIP(ctx, hipStreamSynchronize(st));
+    // (the list is usually left over from the end of the previous round: the pass that looks for the
+    // lowest NEW candidate sees exactly the owners this round starts from unless planes were dropped)
+    if (!cand_listed) {
+      BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
+      cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, nullptr, rpos, d_misc + 1);
+      BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipStreamSynchronize(st));
+    }
+    cand_listed = false;
     if (ncand_all == 0 && npend == 0)
       break;  // no plane attempt left: omega is the final owner array
     if (ncand_all > 0) {
@@ -1215,11 +1226,14 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     }
     if (npend)
       validate2_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, omega, d_neigh, K);
-    int32_t inf = INF;
-    BS_HIP(ctx, hipMemcpyAsync(d_misc + 2, &inf, sizeof inf, hipMemcpyHostToDevice, st));
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, d_misc + 2, nullptr, nullptr);
-    int32_t new_min = INF;
+    // lowest candidate under the new owners (= first attempt that is not established yet) and, in the
+    // same pass, the candidate list of the next round
+    const int32_t init2[2] = {0, INF};
+    BS_HIP(ctx, hipMemcpyAsync(d_misc + 1, init2, sizeof init2, hipMemcpyHostToDevice, st));
+    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, d_misc + 2, rpos, d_misc + 1);
+    int32_t new_min = INF, next_ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
+    BS_HIP(ctx, hipMemcpyAsync(&next_ncand_all, d_misc + 1, sizeof next_ncand_all, hipMemcpyDeviceToHost, st));
     if (ncand)
       BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
     h_pend.resize(npend);
@@ -1347,6 +1361,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       rc = propagate();
       if (rc != BS_OK)
         return rc;
+    } else {
+      cand_listed = true;  // owners unchanged since the candidate pass above: its list is the next round's
+      ncand_all = next_ncand_all;
     }
     pending.swap(next_pending);
     if (pending.empty())
@@ -1384,6 +1401,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   ctx->tm.rg_rounds = rounds;
   ctx->tm.grow_kernel_ms = grow_ms;
   ctx->tm.grow_kernel_launches = grow_launches;
+  {
+    float ms = 0.f;
+    ctx->tm.grow_setup_ms = hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]) == hipSuccess ? (double)ms : 0.0;
+  }
   return BS_OK;
 }
 

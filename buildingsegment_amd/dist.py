@@ -32,7 +32,7 @@ The compute backend is injected so that the orchestration is covered on CPU:
         -> (neigh [n_query,k] i32 GLOBAL indices, normals [n_query,3] f64, n_uncertified)
     region_grow(xyz [n,3], normals [n,3], neigh [n,k], params) -> (labels [n] i32, planes | None)
 `DevBackend` wraps an api.Context (HIP, device pointers); tests/test_dist_gloo.py
-injects the CPU oracle.
+injects a CPU backend of its own.
 """
 from __future__ import annotations
 
@@ -255,7 +255,7 @@ def segment_sharded_dev(backend, d_xyz: torch.Tensor, d_gidx: torch.Tensor, n_to
     grow=False); info carries the slab results (`gidx_own`, `neigh_own`, `normals_own`: this
     rank's Morton slab), `planes` (rank 0 only -- stage 3 is "replicas only", the other ranks
     get None), the halo width used, the retries and per-stage wall times."""
-    if not hasattr(backend, "knn_normals"):
+    if hasattr(backend, "knn_normals_dev"):  # an api.Context: wrap it
         backend = DevBackend(backend)
     world, rank = _world(group), _rank(group)
     dev = d_xyz.device

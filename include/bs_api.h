@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BS_API_VERSION 1
+#define BS_API_VERSION 2
 
 typedef enum bs_status {
   BS_OK = 0,
@@ -89,6 +89,7 @@ typedef struct bs_timings {
   int64_t rg_rounds;      /* speculative rounds (rg_mode 2) */
   double grow_kernel_ms;  /* sum of the plane-growth kernel launches alone (HIP events around each launch) */
   int64_t grow_kernel_launches;
+  double grow_setup_ms;   /* region growing, one-time part: records, static masks, reverse lists, first owner fixed point */
 } bs_timings;
 
 typedef struct bs_ctx bs_ctx;
