@@ -21,7 +21,7 @@ EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "b
            "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_knn_normals_halo", "bs_region_grow", "bs_segment",
            "bs_planes_free", "bs_plane_colors", "bs_knn_normals_dev", "bs_region_grow_dev",
            "bs_segment_dev", "bs_planes_fetch", "bs_shift_to_origin_dev", "bs_plane_colors_dev",
-           "bs_selftest_center_div", "bs_grid_dims", "bs_grid_picture", "bs_grid_picture_dev"]
+           "bs_selftest_center_div", "bs_ingest_dev", "bs_grid_dims", "bs_grid_picture", "bs_grid_picture_dev"]
 
 
 class Params(C.Structure):
@@ -86,6 +86,8 @@ def load():
     L.bs_segment_dev.argtypes = [vp, ip, C.c_int64, pp, ip, dp, ip]
     L.bs_planes_fetch.argtypes = [vp, C.POINTER(Planes)]
     L.bs_shift_to_origin_dev.argtypes = [vp, ip, C.c_int64, ip]
+    L.bs_ingest_dev.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                C.c_int32, ip, ip]
     L.bs_plane_colors_dev.argtypes = [vp, ip, C.c_int32, C.c_int64, vp]
     L.bs_selftest_center_div.argtypes = [vp, ip, vp, ip, C.c_int64]
     L.bs_grid_dims.argtypes = [ip, C.c_int32, ip, ip]

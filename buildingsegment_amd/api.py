@@ -175,6 +175,15 @@ class Context:
         self._check(self._L.bs_shift_to_origin_dev(self._h, d_xyz, n, mn.ctypes.data))
         return mn
 
+    def ingest_dev(self, d_records, n, stride, offsets, is_f64, d_xyz, scale=1000.0, shift_to_origin=True):
+        """ply::read's position quantisation (ply.cpp:436-465) on a device-resident binary vertex body,
+        optionally followed by the buildingSeg shift; returns the subtracted minimum."""
+        mn = np.zeros(3, dtype=np.int32)
+        self._check(self._L.bs_ingest_dev(self._h, d_records, n, stride, offsets[0], offsets[1], offsets[2],
+                                          1 if is_f64 else 0, float(scale), 1 if shift_to_origin else 0, d_xyz,
+                                          mn.ctypes.data))
+        return mn
+
     def plane_colors_dev(self, plane_rgb, n, d_colors):
         rgb = np.ascontiguousarray(plane_rgb, dtype=np.int32).reshape(-1, 3)
         self._check(self._L.bs_plane_colors_dev(self._h, rgb.ctypes.data, len(rgb), n, d_colors))

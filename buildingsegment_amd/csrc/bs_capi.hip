@@ -56,6 +56,55 @@ struct EventTimer {
   }
 };
 
+// foreign neighbour arrays are dereferenced on the device: one streaming pass proves them in range
+__global__ void neigh_range_kernel(const int32_t* __restrict__ neigh, int64_t total, int32_t n, int* bad)
+{
+  bool b = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = neigh[i];
+    b = b || v < 0 || v >= n;
+  }
+  if (__syncthreads_or(b) && threadIdx.x == 0)
+    *bad = 1;
+}
+
+static int region_grow_dev_impl(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
+                                int64_t n, const bs_params* p, int32_t* d_plane_idx, bool trusted_neigh)
+{
+  if (!ctx)
+    return BS_ERR_INVALID;
+  if (!d_xyz || !d_normals || !d_neigh || !d_plane_idx)
+    return fail(ctx, BS_ERR_INVALID, "null device pointer");
+  int rc = check_params(ctx, p, n);
+  if (rc != BS_OK)
+    return rc;
+  BS_HIP(ctx, hipSetDevice(ctx->device));
+  if (!trusted_neigh) {
+    BS_HIP(ctx, ctx->misc.reserve(256));
+    int* d_bad = ctx->misc.as<int>() + 48;
+    BS_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+    const int64_t total = n * (int64_t)p->k;
+    neigh_range_kernel<<<(int)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, ctx->stream>>>(d_neigh, total, (int32_t)n, d_bad);
+    int bad = 0;
+    BS_HIP(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    BS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad)
+      return fail(ctx, BS_ERR_INVALID, "neighbour index out of range");
+  }
+  EventTimer T(ctx);
+  T.mark(3);
+  if (p->rg_mode == 1)
+    rc = launch_region_grow_seq(ctx, d_xyz, d_normals, d_neigh, n, *p, d_plane_idx);
+  else
+    rc = launch_region_grow_spec(ctx, d_xyz, d_normals, d_neigh, n, *p, d_plane_idx);
+  if (rc != BS_OK)
+    return rc;
+  T.mark(4);
+  BS_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
+  ctx->tm.grow_ms = T.ms(3, 4);
+  return BS_OK;
+}
+
 }  // namespace bs
 
 using namespace bs;
@@ -69,7 +118,7 @@ const char* bs_strerror(int status)
   switch (status) {
   case BS_OK: return "ok";
   case BS_ERR_INVALID: return "invalid argument";
-  case BS_ERR_RANGE: return "coordinate outside the exact domain (|c| < 2^23 mm)";
+  case BS_ERR_RANGE: return "coordinate outside the exact domain (|c| < 2^23 mm): shift the cloud to its bounding-box origin first (bs_shift_to_origin_dev / the buildingSeg constructor)";
   case BS_ERR_NOMEM: return "out of memory";
   case BS_ERR_HIP: return "HIP runtime error";
   case BS_ERR_NO_DEVICE: return "no usable HIP device";
@@ -202,26 +251,7 @@ int bs_knn_normals_dev(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx,
 int bs_region_grow_dev(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
                        int64_t n, const bs_params* p, int32_t* d_plane_idx)
 {
-  if (!ctx)
-    return BS_ERR_INVALID;
-  if (!d_xyz || !d_normals || !d_neigh || !d_plane_idx)
-    return fail(ctx, BS_ERR_INVALID, "null device pointer");
-  int rc = check_params(ctx, p, n);
-  if (rc != BS_OK)
-    return rc;
-  BS_HIP(ctx, hipSetDevice(ctx->device));
-  EventTimer T(ctx);
-  T.mark(3);
-  if (p->rg_mode == 1)
-    rc = launch_region_grow_seq(ctx, d_xyz, d_normals, d_neigh, n, *p, d_plane_idx);
-  else
-    rc = launch_region_grow_spec(ctx, d_xyz, d_normals, d_neigh, n, *p, d_plane_idx);
-  if (rc != BS_OK)
-    return rc;
-  T.mark(4);
-  BS_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
-  ctx->tm.grow_ms = T.ms(3, 4);
-  return BS_OK;
+  return region_grow_dev_impl(ctx, d_xyz, d_normals, d_neigh, n, p, d_plane_idx, false);
 }
 
 int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params* p, int32_t* d_neigh,
@@ -248,7 +278,7 @@ int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params
   rc = bs_knn_normals_dev(ctx, d_xyz, nullptr, n, 0, n, p, d_neigh, d_normals, 0.0, nullptr);
   if (rc != BS_OK)
     return rc;
-  rc = bs_region_grow_dev(ctx, d_xyz, d_normals, d_neigh, n, p, d_plane_idx);
+  rc = region_grow_dev_impl(ctx, d_xyz, d_normals, d_neigh, n, p, d_plane_idx, true);  // our own k-lists: in range
   if (rc != BS_OK)
     return rc;
   ctx->tm.total_ms = T.ms(5, 4);
@@ -278,11 +308,16 @@ int bs_planes_fetch(bs_ctx* ctx, bs_planes* out)
     bs_planes_free(out);
     return fail(ctx, BS_ERR_NOMEM, "host allocation failed");
   }
+  hipError_t he = hipSuccess;
   if (np > 0)
-    BS_HIP(ctx, hipMemcpy(recs, ctx->rg_planes.p, sizeof(PlaneRec) * np, hipMemcpyDeviceToHost));
-  if (hs.list_used > 0)
-    BS_HIP(ctx, hipMemcpy(out->point_idx, ctx->rg_list.p, sizeof(int32_t) * hs.list_used,
-                          hipMemcpyDeviceToHost));
+    he = hipMemcpy(recs, ctx->rg_planes.p, sizeof(PlaneRec) * np, hipMemcpyDeviceToHost);
+  if (he == hipSuccess && hs.list_used > 0)
+    he = hipMemcpy(out->point_idx, ctx->rg_list.p, sizeof(int32_t) * hs.list_used, hipMemcpyDeviceToHost);
+  if (he != hipSuccess) {
+    free(recs);
+    bs_planes_free(out);
+    return fail(ctx, BS_ERR_HIP, "bs_planes_fetch: copy of the plane records failed", he);
+  }
   for (int i = 0; i < np; i++) {
     out->id[i] = recs[i].id;
     for (int a = 0; a < 3; a++) {
@@ -413,8 +448,8 @@ int bs_region_grow(bs_ctx* ctx, const int32_t* xyz, const double* normals, const
   BS_HIP(ctx, hipMemcpyAsync(ctx->d_xyz_h.p, xyz, sizeof(int32_t) * 3 * n, hipMemcpyHostToDevice, st));
   BS_HIP(ctx, hipMemcpyAsync(ctx->d_neigh_h.p, neigh, sizeof(int32_t) * n * p->k, hipMemcpyHostToDevice, st));
   BS_HIP(ctx, hipMemcpyAsync(ctx->d_normals_h.p, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-  rc = bs_region_grow_dev(ctx, ctx->d_xyz_h.as<int32_t>(), ctx->d_normals_h.as<double>(),
-                          ctx->d_neigh_h.as<int32_t>(), n, p, ctx->d_plane_h.as<int32_t>());
+  rc = region_grow_dev_impl(ctx, ctx->d_xyz_h.as<int32_t>(), ctx->d_normals_h.as<double>(),
+                            ctx->d_neigh_h.as<int32_t>(), n, p, ctx->d_plane_h.as<int32_t>(), true);
   if (rc != BS_OK)
     return rc;
   BS_HIP(ctx, hipMemcpyAsync(plane_idx, ctx->d_plane_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));

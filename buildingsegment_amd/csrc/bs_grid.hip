@@ -219,7 +219,8 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
   const int32_t LIM = 1 << 23;
   for (int a = 0; a < 3; a++)
     if (bb[a] <= -LIM || bb[3 + a] >= LIM)
-      return fail(ctx, BS_ERR_RANGE, "coordinates must satisfy |c| < 2^23 mm");
+      return fail(ctx, BS_ERR_RANGE, "coordinates must satisfy |c| < 2^23 mm (8.4 km): shift the cloud to its bounding-box origin first "
+                                     "(bs_shift_to_origin_dev, or the buildingSeg constructor as TMC3.cpp:210 does)");
 
   // 2. cell size: >= radius so one ring certifies the hybrid search, and a
   // density-driven size giving ~max(4, k/2) points per occupied cell

@@ -572,7 +572,11 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       // settle last call's optimistic claims
       const bool lost = pend && pend_old <= seed;  // an earlier plane got there first (or a double claim)
       if (pend && pend_old > seed && pend_old != INF)
-        dead[pend_old] = seed + 1;  // took it from a later plane: that plane is invalid (value: thief + 1)
+        // took it from a later plane: that plane is invalid (value: thief + 1).  dead[] is read and written by
+        // waves on other XCDs: agent-scope atomics only.  The mark is ADVISORY (it ends a doomed attempt early
+        // and lets it re-grow inside the launch); the safety net is the post-round validation, which re-checks
+        // every list entry's claim and replays every decision (validate1 / validate3).
+        __hip_atomic_store(dead + pend_old, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pend = false;
       if (__builtin_expect(killed || ballot64(lost), 0)) {
         status = ST_STOLEN;
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   // otherwise the victim could reclaim the point from this (dead) plane and end
   // up holding it twice without ever being invalidated.
   if (pend && pend_old > seed && pend_old != INF)
-    dead[pend_old] = seed + 1;
+    __hip_atomic_store(dead + pend_old, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (status == ST_DONE) {
     const bool lost = pend && pend_old <= seed;
     if (ballot64(lost))

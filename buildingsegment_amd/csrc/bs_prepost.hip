@@ -58,10 +58,81 @@ __global__ void color_scatter_kernel(const PlaneRec* __restrict__ planes, const 
   }
 }
 
+// PLY ingest on the device: one thread per vertex record of a binary
+// little-endian body; position = (int32) trunc(value * scale) exactly as ply.cpp:436-465
+// (float promoted to double, double product, C conversion toward zero), AoS int32 out.
+// Records are byte-packed (27 B, 15 B, ...): fields are assembled from bytes.
+__device__ inline double load_scalar_le(const unsigned char* p, int is_f64)
+{
+  if (is_f64) {
+    unsigned long long b = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+      b |= (unsigned long long)p[t] << (8 * t);
+    return __longlong_as_double((long long)b);
+  }
+  unsigned int b = 0;
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+    b |= (unsigned int)p[t] << (8 * t);
+  return (double)__uint_as_float(b);
+}
+
+__global__ void ingest_kernel(const unsigned char* __restrict__ rec, int64_t n, int stride, int ox, int oy, int oz,
+                              int is_f64, double scale, int32_t* __restrict__ xyz, int* __restrict__ bad)
+{
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const unsigned char* r = rec + i * stride;
+  const double v[3] = {load_scalar_le(r + ox, is_f64) * scale, load_scalar_le(r + oy, is_f64) * scale,
+                       load_scalar_le(r + oz, is_f64) * scale};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    // outside int32 the reference's conversion is undefined behaviour: report instead
+    if (!(v[a] > -2147483649.0 && v[a] < 2147483648.0))
+      *bad = 1;
+    xyz[3 * i + a] = (int32_t)v[a];
+  }
+}
+
 }  // namespace
 }  // namespace bs
 
 using namespace bs;
+
+extern "C" int bs_shift_to_origin_dev(bs_ctx* ctx, int32_t* d_xyz, int64_t n, int32_t* min_out);
+
+extern "C" int bs_ingest_dev(bs_ctx* ctx, const void* d_records, int64_t n, int32_t stride, int32_t off_x, int32_t off_y,
+                             int32_t off_z, int32_t is_f64, double scale, int32_t shift_to_origin, int32_t* d_xyz,
+                             int32_t* min_out)
+{
+  if (!ctx)
+    return BS_ERR_INVALID;
+  const int w = is_f64 ? 8 : 4;
+  if (!d_records || !d_xyz || n <= 0 || stride < 3 * w || off_x < 0 || off_y < 0 || off_z < 0 || off_x + w > stride ||
+      off_y + w > stride || off_z + w > stride)
+    return fail(ctx, BS_ERR_INVALID, "bs_ingest_dev: null pointer or inconsistent record layout");
+  BS_HIP(ctx, hipSetDevice(ctx->device));
+  BS_HIP(ctx, ctx->misc.reserve(256));
+  hipStream_t st = ctx->stream;
+  int* d_bad = ctx->misc.as<int>() + 56;
+  BS_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(int), st));
+  ingest_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>((const unsigned char*)d_records, n, stride, off_x, off_y, off_z,
+                                                      is_f64, scale, d_xyz, d_bad);
+  int bad = 0;
+  BS_HIP(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
+  BS_HIP(ctx, hipStreamSynchronize(st));
+  BS_HIP(ctx, hipGetLastError());
+  if (bad)
+    return fail(ctx, BS_ERR_RANGE, "bs_ingest_dev: value * scale does not fit int32 (undefined in the reference, ply.cpp:436-465)");
+  if (shift_to_origin)
+    return bs_shift_to_origin_dev(ctx, d_xyz, n, min_out);
+  if (min_out)
+    min_out[0] = min_out[1] = min_out[2] = 0;
+  ctx->order_n = 0;
+  return BS_OK;
+}
 
 extern "C" int bs_shift_to_origin_dev(bs_ctx* ctx, int32_t* d_xyz, int64_t n, int32_t* min_out)
 {

@@ -180,6 +180,19 @@ int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params
  * (G,B,R slots) zeroed, then plane_rgb[p] (host, [n_planes][3]) scattered to
  * every pointIdx entry of plane p. */
 int bs_shift_to_origin_dev(bs_ctx* ctx, int32_t* d_xyz, int64_t n, int32_t* min_out);
+
+/* PLY ingest on the device (replaces the per-property loop of
+ * ply::read, ply.cpp:431-501, for the positions): d_records is the binary
+ * little-endian vertex body resident on the device (n records of `stride` bytes,
+ * x/y/z at byte offsets off_x/off_y/off_z, all three float32 (is_f64 = 0) or
+ * float64).  d_xyz [n][3] receives (int32) trunc(value * scale) (ply.cpp:436-465;
+ * float promoted to double first).  shift_to_origin != 0 additionally applies the
+ * buildingSeg constructor's bounding-box shift (TMC3.cpp:55-73) and reports the
+ * subtracted minimum in min_out (host [3], nullable).  BS_ERR_RANGE if a product
+ * does not fit int32 (undefined behaviour in the reference).  Synchronises. */
+int bs_ingest_dev(bs_ctx* ctx, const void* d_records, int64_t n, int32_t stride, int32_t off_x, int32_t off_y,
+                  int32_t off_z, int32_t is_f64, double scale, int32_t shift_to_origin, int32_t* d_xyz,
+                  int32_t* min_out);
 int bs_plane_colors_dev(bs_ctx* ctx, const int32_t* plane_rgb, int32_t n_planes, int64_t n, uint16_t* d_colors);
 
 /* 2-D density / height raster: the reference's (currently commented-out) 2-D

@@ -28,3 +28,6 @@ echo "built $OUT/ref_stage3"
 } > "$TMP/ref_raster.cpp"
 g++ -std=c++17 -O2 -DNDEBUG -w -I"$REF" "$TMP/ref_raster.cpp" -o "$OUT/ref_raster"
 echo "built $OUT/ref_raster"
+# the PLY reader / writer: the reference's ply.cpp compiled where it lies, plus a driver
+g++ -std=c++17 -O2 -DNDEBUG -w -I"$REF" "$REF/ply.cpp" "$HERE/ref_ply_driver.cpp" -o "$OUT/ref_ply"
+echo "built $OUT/ref_ply"
