@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-              if not os.path.basename(p).startswith("raster_"))  # stage-3 fixtures (the raster ones: test_*raster.py)
+              if not os.path.basename(p).startswith(("raster_", "ply_")))  # stage-3 fixtures (raster / PLY ones have their own tests)
 
 
 def test_fixtures_present():
