@@ -419,10 +419,19 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   uint32_t iters = 0;
   const uint32_t iter_cap = step_cap > 0xFFFFFFF0ll ? 0xFFFFFFF0u : (uint32_t)step_cap;
   int status = ST_DONE;
-  // optimistic claims: the atomicMin of call i is only checked in call i+1,
-  // after the next gather has been issued (its latency hides the atomic's)
-  bool pend = false;
-  int pend_old = INF;
+  // Optimistic claims.  A claim is a NO-RETURN atomicMin on the record's tag (a returning atomic
+  // keeps the wave waiting 600-950 cycles for a value that is rarely interesting).  What the
+  // returned value used to tell is recovered without a wait:
+  //  * "I took the point from a LATER plane": the tag read by this call's gather (tg > seed)
+  //    names the victim, which is marked at claim time;
+  //  * "an EARLIER plane got there first": the tag is read back by the NEXT call's gather
+  //    (same wave, same address: the load observes the atomic) -- anything but my seed means lost.
+  // A later plane that claims between my gather and my atomic is not marked by me, but reads the
+  // tag back itself one call later and sees my seed.  Whatever slips through these advisory
+  // checks is caught after the round: validate1 re-reads every list entry's tag and rejects
+  // duplicated entries.
+  bool pendv = false;
+  const int32_t* vptr = dead;  // tag word claimed by the previous call (any valid address while !pendv)
   bool need_state = false;
   const int4* srec = rec + (int64_t)seed * Q;
   const int4 s0 = srec[0], s1 = srec[1], s2 = srec[2];
@@ -467,8 +476,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   // Chains of planes that depend on each other thus resolve inside ONE launch.
   for (int attempt = 0;; attempt++) {
   status = ST_DONE;
-  pend = false;
-  pend_old = INF;
+  pendv = false;
   ln = 1;
   sp = 0;
   lds_lo = 0;
@@ -527,6 +535,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
       if (valid && act)
         cand_id = lds_stack[(e & (LDS_STACK - 1)) * KC + j + 1];
       const int killed = ld_i32(dead + seed);  // an earlier plane took one of my points: I am invalid
+      const int vt = ld_i32(pendv ? vptr : dead + seed);  // read-back of the previous call's claim
       int own = 0, tg = INF, px = 0, py = 0, pz = 0;
       double mx = 0, my = 0, mz = 0;
       int row[KC];  // only read from lanes that loaded it (the accepting lanes)
@@ -569,15 +578,9 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         const double dt = cnx * mx + cny * my + cnz * mz;
         geo = dist <= a.th && dt >= a.cos_th;
       }
-      // settle last call's optimistic claims
-      const bool lost = pend && pend_old <= seed;  // an earlier plane got there first (or a double claim)
-      if (pend && pend_old > seed && pend_old != INF)
-        // took it from a later plane: that plane is invalid (value: thief + 1).  dead[] is read and written by
-        // waves on other XCDs: agent-scope atomics only.  The mark is ADVISORY (it ends a doomed attempt early
-        // and lets it re-grow inside the launch); the safety net is the post-round validation, which re-checks
-        // every list entry's claim and replays every decision (validate1 / validate3).
-        __hip_atomic_store(dead + pend_old, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pend = false;
+      // settle last call's optimistic claims: the tag must carry my seed
+      const bool lost = pendv && vt != seed;  // an earlier plane got there first
+      pendv = false;
       if (__builtin_expect(killed || ballot64(lost), 0)) {
         status = ST_STOLEN;
         return 2;
@@ -599,8 +602,12 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
         if (__builtin_expect((earlier & gm1) == 0, 1)) {
           ok = contender && g == g1;
           if (ok) {
-            pend_old = atomicMin(rec_tag(rec, Q, cand_id), seed);
-            pend = true;
+            int32_t* tp = rec_tag(rec, Q, cand_id);
+            __hip_atomic_fetch_min(tp, seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // result unused: no-return form
+            if (tg != INF)  // held by a later plane (tg > seed here): it is invalid now (value: thief + 1)
+              __hip_atomic_store(dead + tg, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vptr = tp;
+            pendv = true;
           }
           am = cm & gm1;
           gstar = g1;
@@ -630,10 +637,17 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
                   }
                 } else if (cur_tag == seed) {
                   mine = true;
-                } else {  // free, or held by a later plane: claim, verify next call
-                  pend_old = atomicMin(tp, seed);
-                  pend = true;
-                  ok = true;
+                } else {  // free, or held by a later plane: claim (rare path: returning atomic, settled at once)
+                  const int old = atomicMin(tp, seed);
+                  if (old > seed) {
+                    if (old != INF)
+                      __hip_atomic_store(dead + old, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = true;
+                  } else if (old == seed) {
+                    mine = true;
+                  } else {
+                    cur_tag = old;  // an earlier plane got there between the gather and the claim: look again
+                  }
                 }
               }
               if (!ok && !mine)
@@ -738,15 +752,9 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   }
   if (need_state)  // state of the very last expansion (the plane's reported normal / centre)
     update_state();
-  // Settle the claims of the last call on EVERY exit path (normal end, failed
-  // depth 0, pool exhaustion, kill): a plane that took a point from a later
-  // plane must mark that plane invalid even if it does not survive itself --
-  // otherwise the victim could reclaim the point from this (dead) plane and end
-  // up holding it twice without ever being invalidated.
-  if (pend && pend_old > seed && pend_old != INF)
-    __hip_atomic_store(dead + pend_old, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Read back the claims of the very last call (victims were marked at claim time on every path).
   if (status == ST_DONE) {
-    const bool lost = pend && pend_old <= seed;
+    const bool lost = pendv && ld_i32(vptr) != seed;
     if (ballot64(lost))
       status = ST_STOLEN;
   }
@@ -801,7 +809,8 @@ constexpr int VT = 1024;
 
 // every accepted point must still carry this plane's claim
 __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
-                                                       int4* rec, int quads, const int32_t* __restrict__ dead, int64_t n)
+                                                       int4* rec, int quads, const int32_t* __restrict__ dead, int64_t n,
+                                                       int32_t* __restrict__ vmark, int32_t round_key)
 {
   const int w = blockIdx.x;
   if (w >= ncand || out[w].status != ST_DONE)
@@ -809,8 +818,16 @@ __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand,
   const PlaneOut o = out[w];
   // lost a point after it had finished, or an impossible list (each point at most once + the seed)
   bool bad = dead[o.seed] != 0 || o.list_n > n + 1;
-  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT)
-    bad = bad || *rec_tag(rec, quads, pool[o.list_off + t]) != o.seed;
+  // ... and no point may be listed twice (the claim protocol inside the launch is advisory; a plane that
+  // reclaimed a point it already held would pass the tag test).  vmark[p] receives a key that is unique
+  // per (round, plane): meeting one's own key again is a duplicate.  The seed's second appearance (quirk
+  // Q1: it is pushed at position 0 without a label and can be accepted once more) is legal, once.
+  const int32_t key = round_key + w + 1;
+  for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT) {
+    const int32_t p = pool[o.list_off + t];
+    bad = bad || *rec_tag(rec, quads, p) != o.seed;
+    bad = bad || atomicExch(&vmark[p], key) == key;
+  }
   const int b = __syncthreads_or(bad);  // (also orders the reads of out[w] above before the write below)
   if (threadIdx.x == 0) {
     if (b)
@@ -1006,6 +1023,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int32_t* dead = aux + 1024 + 3 * n;
   int32_t* d_cand = aux + 1024 + 4 * n;  // select output (n entries)
   int32_t* rpos = aux + 1024 + 5 * n;    // n + 1 (+ pad): reverse-list counts / fill cursors, later the candidate scratch
+  int32_t* vmark = aux + 1024 + 6 * n + 64;    // duplicate detection of validate1 (n entries)
   int32_t* d_seeds = aux + 1024 + 7 * n + 64;  // committed seeds (planes_cap)
   uint8_t* flags = (uint8_t*)(aux + n_i32);
   uint8_t* ps = flags + n;
@@ -1060,6 +1078,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, n, INF);
   BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
+  BS_HIP(ctx, hipMemsetAsync(vmark, 0, sizeof(int32_t) * n, st));
   BS_HIP(ctx, hipMemsetAsync(occ, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(dirty0, 1, n, st));
   BS_HIP(ctx, hipMemsetAsync(dirty1, 0, n, st));
@@ -1219,7 +1238,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
-      validate1_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n);
+      validate1_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n, vmark,
+                                             (int32_t)((rounds & 0x3fff) << 17));
       reset_tags_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, d_neigh, K);
       // insert the finished planes and let the owners settle
       plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur);
