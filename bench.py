@@ -207,6 +207,7 @@ def measure_single(ctx, api, torch, dev, name, k_override, rg_mode, steps, warmu
            "value": world * n * steps / elapsed / 1e6, "unit": "Mpoints/s", "ms_per_step": elapsed / max(steps, 1) * 1e3,
            "stages_ms": stage, "rg_rounds": tm["rg_rounds"], "largest_plane": tm["largest_plane"],
            "seed_attempts": tm["n_seed_attempts"], "fallback_queries": tm["n_fallback_queries"],
+           "validation_rejects": tm["validation_rejects"],
            "end_to_end_alg_GBps": n * (88 + 8 * k) / (elapsed / max(steps, 1)) / 1e9,
            "roofline": roofline_block(n, k, stage, launches / max(steps, 1), rg_mode, name),
            "radius_mm": params.radius, "max_nn": params.max_nn}
@@ -291,6 +292,7 @@ def main():
                                    "radius_mm": res["radius_mm"], "max_nn": res["max_nn"], "rg_mode": args.rg_mode,
                                    "largest_plane": res["largest_plane"], "seed_attempts": res["seed_attempts"],
                                    "fallback_queries": res["fallback_queries"], "rg_rounds": res["rg_rounds"],
+                                   "validation_rejects": res["validation_rejects"],
                                    "parallelism": "1 GPU, whole path" if world == 1 else f"{world} independent replicas"},
                         "stages_ms": res["stages_ms"], "end_to_end_alg_GBps": res["end_to_end_alg_GBps"],
                         "roofline": res["roofline"]})

@@ -215,6 +215,11 @@ class Context:
         self._check(self._L.bs_selftest_center_div(self._h, c.ctypes.data, n.ctypes.data, out.ctypes.data, len(c)))
         return out
 
+    def selftest_forge_next(self, mode):
+        """The next region grow corrupts one finished plane (1: duplicated entry, 2: normal off by an ulp);
+        timings()['validation_rejects'] must then be >= 1 and the result still exact."""
+        self._check(self._L.bs_selftest_forge_next(self._h, int(mode)))
+
     def planes_fetch(self):
         P = Planes()
         self._check(self._L.bs_planes_fetch(self._h, C.byref(P)))

@@ -285,6 +285,14 @@ int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params
   return BS_OK;
 }
 
+int bs_selftest_forge_next(bs_ctx* ctx, int mode)
+{
+  if (!ctx || mode < 0 || mode > 2)
+    return BS_ERR_INVALID;
+  ctx->forge_mode = mode;
+  return BS_OK;
+}
+
 int bs_planes_fetch(bs_ctx* ctx, bs_planes* out)
 {
   if (!ctx || !out)

@@ -126,6 +126,7 @@ struct bs_ctx {
   bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec, rg_radj, rg_roff;
   int64_t rg_n = 0;
   bool rg_valid = false;
+  int forge_mode = 0;  // bs_selftest_forge_next
   // 2-D raster scratch (bs_raster.hip)
   bs::DevBuf rs_keys_in, rs_keys_out, rs_vals_in, rs_vals_out, rs_cnt, rs_img, rs_tmp;
   // cell-sorted order of the last grid build (vals_out): spatially coherent iteration for gathers

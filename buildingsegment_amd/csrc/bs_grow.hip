@@ -278,6 +278,9 @@ int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_no
       ctx->tm.grow_kernel_ms = ms;
     ctx->tm.grow_kernel_launches = 1;
     ctx->tm.grow_setup_ms = 0.0;
+    ctx->tm.validation_rejects = 0;
+    ctx->tm.forged_seed = -1;
+    ctx->tm.forged_refused = 0;
   }
   return BS_OK;
 }

@@ -810,7 +810,7 @@ constexpr int VT = 1024;
 // every accepted point must still carry this plane's claim
 __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
                                                        int4* rec, int quads, const int32_t* __restrict__ dead, int64_t n,
-                                                       int32_t* __restrict__ vmark, int32_t round_key)
+                                                       int32_t* __restrict__ vmark, int32_t round_key, int* rejects)
 {
   const int w = blockIdx.x;
   if (w >= ncand || out[w].status != ST_DONE)
@@ -826,14 +826,151 @@ __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand,
   for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT) {
     const int32_t p = pool[o.list_off + t];
     bad = bad || *rec_tag(rec, quads, p) != o.seed;
-    bad = bad || atomicExch(&vmark[p], key) == key;
+    const bool dup = atomicExch(&vmark[p], key) == key;
+    if (dup)
+      atomicAdd(rejects, 1);
+    bad = bad || dup;
   }
   const int b = __syncthreads_or(bad);  // (also orders the reads of out[w] above before the write below)
   if (threadIdx.x == 0) {
-    if (b)
+    if (b) {
       out[w].status = ST_STOLEN;
-    else
+      if (rejects[1] == o.seed + 1)
+        rejects[2] = 1;  // the plane the self-test forged was refused
+    } else {
       out[w].pad = 1;  // insert command for plane_apply_kernel
+    }
+  }
+}
+
+// validate3: the plane's reported state must follow from its list.  The reference re-sums every
+// member in pointIdx order (my_function.cpp:241-250): normal = S / sqrt(S.S) with S the f64 sum of the
+// members' normals IN LIST ORDER from +0 (quirk Q7), centre = (int32)((uint64)(int64)(int32)C / size)
+// with C the wrapping int32 coordinate sum (quirk Q3).  Both are recomputed here from the finished list
+// and the records alone -- independently of the running sums the growth kernel carried -- and must
+// equal the reported values bit for bit.  Together with validate1 (every entry still carries the
+// plane's claim, no entry twice) this rejects the failure signature of every claim-protocol bug seen
+// so far (a point held twice: duplicated entry, wrong normal / centre) instead of relying on repeated
+// fuzzing to expose it.  The f64 sum is inherently sequential: wave 0 stages 64 normals per trip in
+// LDS and one lane adds them in order (three independent chains); the other waves form the
+// order-independent integer sum.
+constexpr int V3T = 256;
+__global__ __launch_bounds__(V3T) void validate3_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
+                                                        const int4* __restrict__ rec, int quads, int* rejects)
+{
+  __shared__ double sn[2][64][3];
+  __shared__ uint32_t sc[V3T / 64][3];
+  const int w = blockIdx.x;
+  if (w >= ncand || out[w].status != ST_DONE || out[w].pad != 1)  // pad == 1: passed validate1
+    return;
+  const PlaneOut o = out[w];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // integer sum (wraps mod 2^32): all threads
+  uint32_t cx = 0, cy = 0, cz = 0;
+  for (int64_t t = tid; t < o.list_n; t += V3T) {
+    const int4 q0 = rec[(int64_t)pool[o.list_off + t] * quads];
+    cx += (uint32_t)q0.x;
+    cy += (uint32_t)q0.y;
+    cz += (uint32_t)q0.z;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cx += (uint32_t)__shfl_xor((int)cx, off);
+    cy += (uint32_t)__shfl_xor((int)cy, off);
+    cz += (uint32_t)__shfl_xor((int)cz, off);
+  }
+  if (lane == 0) {
+    sc[wv][0] = cx;
+    sc[wv][1] = cy;
+    sc[wv][2] = cz;
+  }
+  // f64 sum in list order: wave 0, double-buffered staging
+  double Sx = 0.0, Sy = 0.0, Sz = 0.0;
+  if (wv == 0) {
+    const int64_t trips = (o.list_n + 63) / 64;
+    double rx = 0, ry = 0, rz = 0;
+    auto fetch = [&](int64_t trip) {  // the next 64 normals into registers (loads in flight during the adds)
+      const int64_t t = trip * 64 + lane;
+      if (t < o.list_n) {
+        const int4* r = rec + (int64_t)pool[o.list_off + t] * quads;
+        const int4 q1 = r[1], q2 = r[2];
+        rx = __hiloint2double(q1.y, q1.x);
+        ry = __hiloint2double(q1.w, q1.z);
+        rz = __hiloint2double(q2.y, q2.x);
+      }
+    };
+    auto put = [&](int buf) {
+      sn[buf][lane][0] = rx;
+      sn[buf][lane][1] = ry;
+      sn[buf][lane][2] = rz;
+    };
+    fetch(0);
+    put(0);
+    for (int64_t trip = 0; trip < trips; trip++) {
+      const int buf = (int)(trip & 1);
+      if (trip + 1 < trips)
+        fetch(trip + 1);
+      const int cnt = (int)((o.list_n - trip * 64 < 64) ? o.list_n - trip * 64 : 64);
+      if (lane == 0) {  // LDS operations of one wave complete in issue order: the values put() wrote are visible
+        for (int e = 0; e < cnt; e++) {
+          Sx += sn[buf][e][0];
+          Sy += sn[buf][e][1];
+          Sz += sn[buf][e][2];
+        }
+      }
+      if (trip + 1 < trips)
+        put(buf ^ 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t Cx = 0, Cy = 0, Cz = 0;
+    for (int k = 0; k < V3T / 64; k++) {
+      Cx += sc[k][0];
+      Cy += sc[k][1];
+      Cz += sc[k][2];
+    }
+    bool same;
+    if (o.list_n == 1) {  // a seed alone never finishes as ST_DONE; kept for completeness
+      same = true;
+    } else {
+      const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+      const double nx = Sx / nrm, ny = Sy / nrm, nz = Sz / nrm;
+      const CenterDiv cd = center_div_prepare((uint32_t)o.list_n);
+      const int32_t ex = center_div((int32_t)Cx, cd), ey = center_div((int32_t)Cy, cd), ez = center_div((int32_t)Cz, cd);
+      same = __double_as_longlong(nx) == __double_as_longlong(o.normal[0]) &&
+             __double_as_longlong(ny) == __double_as_longlong(o.normal[1]) &&
+             __double_as_longlong(nz) == __double_as_longlong(o.normal[2]) && ex == o.center[0] && ey == o.center[1] &&
+             ez == o.center[2];
+    }
+    if (!same) {
+      out[w].status = ST_STOLEN;  // never enters the structure; its seed is grown again next round
+      out[w].pad = 0;
+      atomicAdd(rejects, 1);
+      if (rejects[1] == o.seed + 1)
+        rejects[2] = 1;
+    }
+  }
+}
+
+// Self-test hook (bs_selftest_forge_next): corrupts the FIRST finished plane of a round the way the
+// claim-protocol bugs of round 1 did, so that a test can watch the validation reject it.
+//   mode 1: one list entry is appended once more (a point held twice);
+//   mode 2: the reported normal is off by one unit in the last place.
+__global__ void forge_kernel(PlaneOut* out, int ncand, int32_t* pool, int mode, int* forged)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0)
+    return;
+  for (int w = 0; w < ncand; w++) {
+    const int64_t ln = out[w].list_n;
+    if (out[w].status != ST_DONE || ln < 64 || (ln & (ln - 1)) == 0)  // (a power of two may fill its slab exactly)
+      continue;
+    if (mode == 1) {
+      pool[out[w].list_off + ln] = pool[out[w].list_off + 20];  // entry 20 once more, at the end
+      out[w].list_n = ln + 1;
+    } else
+      out[w].normal[2] = __longlong_as_double(__double_as_longlong(out[w].normal[2]) ^ 1ll);
+    *forged = out[w].seed + 1;
+    return;
   }
 }
 
@@ -1183,6 +1320,12 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   };
   bool cand_listed = false;
   int32_t ncand_all = 0;
+  int32_t rejects_seen = 0;
+  int refused_rounds = 0;
+  int forge_mode = ctx->forge_mode;
+  ctx->forge_mode = 0;
+  const bool do_validate3 = getenv("BS_NO_VALIDATE3") == nullptr;  // developer A/B switch
+  BS_HIP(ctx, hipMemsetAsync(d_misc + 4, 0, 3 * sizeof(int), st));  // [4] refused planes, [5] forged seed + 1, [6] forged one refused
   for (;;) {
     rounds++;
     a.F = F;
@@ -1238,8 +1381,14 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
+      if (forge_mode) {  // self-test: corrupt one finished plane (see forge_kernel); once per call
+        forge_kernel<<<1, 64, 0, st>>>(d_out, ncand, pool.base, forge_mode, d_misc + 5);
+        forge_mode = 0;
+      }
       validate1_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n, vmark,
-                                             (int32_t)((rounds & 0x3fff) << 17));
+                                             (int32_t)((rounds & 0x3fff) << 17), d_misc + 4);
+      if (do_validate3)
+        validate3_kernel<<<ncand, V3T, 0, st>>>(d_out, ncand, pool.base, rec, quads, d_misc + 4);
       reset_tags_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, d_neigh, K);
       // insert the finished planes and let the owners settle
       plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur);
@@ -1258,6 +1407,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     int32_t new_min = INF, next_ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipMemcpyAsync(&next_ncand_all, d_misc + 1, sizeof next_ncand_all, hipMemcpyDeviceToHost, st));
+    int32_t rejects_now = 0;
+    BS_HIP(ctx, hipMemcpyAsync(&rejects_now, d_misc + 4, sizeof rejects_now, hipMemcpyDeviceToHost, st));
     if (ncand)
       BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
     h_pend.resize(npend);
@@ -1394,8 +1545,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       pstore_top = 0;
     if (first_bad == INF)
       break;  // every plane attempt is final; omega holds the remaining orphan makers' fixed point
-    if (finals == 0 && dropped == 0 && !nomem_lowest && first_bad <= F)
-      return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): no progress");
+    // a plane the validation refused is simply grown again; only a refusal that repeats is fatal
+    const bool refused = rejects_now > rejects_seen;
+    rejects_seen = rejects_now;
+    refused_rounds = refused ? refused_rounds + 1 : 0;
+    if (finals == 0 && dropped == 0 && !nomem_lowest && first_bad <= F && (!refused || refused_rounds > 8))
+      return fail(ctx, BS_ERR_INTERNAL, refused ? "region grow (speculative): the validation keeps refusing a plane"
+                                                : "region grow (speculative): no progress");
     F = first_bad;
     if (rounds > 4 * n + 16)
       return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): round limit");
@@ -1408,6 +1564,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, hipMemcpyAsync(ctx->rg_planes.p, recs.data(), sizeof(PlaneRec) * np, hipMemcpyHostToDevice, st));
   }
   label_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, d_seeds, np, d_plane_idx);
+  int32_t vstat[3] = {0, 0, 0};
+  BS_HIP(ctx, hipMemcpyAsync(vstat, d_misc + 4, sizeof vstat, hipMemcpyDeviceToHost, st));
   GrowStats hs;
   hs.n_planes = np;
   hs.error = 0;
@@ -1425,6 +1583,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   ctx->tm.rg_rounds = rounds;
   ctx->tm.grow_kernel_ms = grow_ms;
   ctx->tm.grow_kernel_launches = grow_launches;
+  ctx->tm.validation_rejects = vstat[0];
+  ctx->tm.forged_seed = vstat[1] - 1;
+  ctx->tm.forged_refused = vstat[2];
   {
     float ms = 0.f;
     ctx->tm.grow_setup_ms = hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]) == hipSuccess ? (double)ms : 0.0;

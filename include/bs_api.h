@@ -90,6 +90,10 @@ typedef struct bs_timings {
   double grow_kernel_ms;  /* sum of the plane-growth kernel launches alone (HIP events around each launch) */
   int64_t grow_kernel_launches;
   double grow_setup_ms;   /* region growing, one-time part: records, static masks, reverse lists, first owner fixed point */
+  int64_t validation_rejects; /* finished planes (or duplicated list entries) the post-round validation refused;
+                                 refused planes are grown again, the result stays exact */
+  int64_t forged_seed;        /* seed of the plane bs_selftest_forge_next corrupted, -1 if none */
+  int64_t forged_refused;     /* 1 if the validation refused exactly that plane */
 } bs_timings;
 
 typedef struct bs_ctx bs_ctx;
@@ -226,6 +230,13 @@ int bs_grid_picture_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const int3
  * device version rests on the hardware reciprocal seed, which no host test can
  * exercise; tests/test_gpu_parity.py checks millions of pairs through this. */
 int bs_selftest_center_div(bs_ctx* ctx, const int32_t* c, const uint32_t* n, int32_t* out, int64_t count);
+
+/* Self-test of the grower's post-round validation: the NEXT region grow on this context corrupts one
+ * finished plane before validating it -- mode 1: a list entry duplicated (a point held twice), mode 2:
+ * the reported normal off by one ulp -- the way the claim-protocol bugs found by fuzzing did.  The
+ * validation must refuse the plane (bs_timings.forged_refused == 1, forged_seed names it); it is
+ * then grown again and the final result is still exact. */
+int bs_selftest_forge_next(bs_ctx* ctx, int mode);
 
 /* Copy the plane records of the last region-grow on this context to the host. */
 int bs_planes_fetch(bs_ctx* ctx, bs_planes* planes);

@@ -379,3 +379,32 @@ def test_regression_fuzz_2718_16_reclaim_aba():
                           "--only", "16", "--repeat", "25"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "0 mismatches" in out.stdout
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_validation_rejects_a_forged_plane(gpu_ctx, oracle, mode):
+    """The post-round validation is a certificate, not a smoke test: a finished plane whose list holds a point
+    twice (mode 1) or whose reported normal differs from the sum over its list by one ulp (mode 2) -- the
+    signatures of the claim-protocol bugs found by fuzzing in round 1 -- must be refused (validate1 /
+    validate3 in bs_grow_spec.hip), grown again, and the final result must still equal the oracle's.
+    (my_function.cpp:226-233,241-250)"""
+    from buildingsegment_amd import api, synth
+    xyz = synth.plane_cube()[:40000].copy()
+    neigh, normals = oracle.knn_normals(xyz, k=15)
+    opi, opl = oracle.region_grow(xyz, normals, neigh)
+    p = api.default_params(k=15)
+    gpu_ctx.region_grow(xyz, normals, neigh, p)
+    assert gpu_ctx.timings()["forged_seed"] == -1 and gpu_ctx.timings()["forged_refused"] == 0
+    rounds_clean = gpu_ctx.timings()["rg_rounds"]
+    gpu_ctx.selftest_forge_next(mode)
+    pi, planes = gpu_ctx.region_grow(xyz, normals, neigh, p)
+    tm = gpu_ctx.timings()
+    assert tm["forged_seed"] >= 0, "no plane was forged"
+    assert tm["forged_refused"] == 1 and tm["validation_rejects"] >= 1, "the forged plane passed the validation"
+    assert tm["rg_rounds"] > rounds_clean  # ... and was grown again
+    assert np.array_equal(pi, opi) and len(planes) == len(opl["id"])
+    assert np.array_equal(np.concatenate([q.pointIdx for q in planes]), opl["point_idx"])
+    assert np.array_equal(np.stack([q.normal for q in planes]), opl["normal"])
+    assert np.array_equal(np.stack([q.center for q in planes]), opl["center"])
+    gpu_ctx.region_grow(xyz, normals, neigh, p)  # the hook is one-shot
+    assert gpu_ctx.timings()["forged_seed"] == -1
