@@ -157,7 +157,8 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
 // order), so that the neighbour gathers of adjacent threads share cache lines.
 // Neighbour geometry comes from the one-line-per-point records.
 __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order, const int4* __restrict__ rec,
-                                   int quads, uint32_t* __restrict__ hmask, int32_t* __restrict__ rcnt)
+                                   const int4* __restrict__ geo, int quads, uint32_t* __restrict__ hmask,
+                                   int32_t* __restrict__ rcnt)
 {
   const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
   if (s >= a.n)
@@ -171,8 +172,9 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
   const int32_t* row = reinterpret_cast<const int32_t*>(ri + 4);
   uint32_t m = 0;
   for (int t = 1; t < a.K; t++) {
-    const int4* rc = rec + (int64_t)row[t] * quads;
-    const int4 q0 = rc[0], q1 = rc[1], q2 = rc[2];
+    const int4* rc = geo + (int64_t)row[t] * 4;
+    const int4 q0 = rc[0], q1 = rc[1];
+    const int2 q2 = *reinterpret_cast<const int2*>(rc + 2);
     const int dx = (int)((uint32_t)q0.x - (uint32_t)ccx);
     const int dy = (int)((uint32_t)q0.y - (uint32_t)ccy);
     const int dz = (int)((uint32_t)q0.z - (uint32_t)ccz);
@@ -196,8 +198,8 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
 // indices, so the iteration settles bottom-up to the unique fixed point; work is
 // proportional to what actually changes, not to n.
 __global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                int64_t n, const int32_t* __restrict__ order, const int64_t* __restrict__ roff,
-                                int32_t* __restrict__ rpos, int32_t* __restrict__ radj)
+                                int64_t n, const int32_t* __restrict__ order, unsigned long long* __restrict__ rcur,
+                                int32_t* __restrict__ radj)
 {
   const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
   if (s >= n)
@@ -209,14 +211,14 @@ __global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_
     const int t = __ffs(m) - 1;
     m &= m - 1;
     const int32_t c = row[t + 1];
-    radj[roff[c] + atomicAdd(&rpos[c], 1)] = (int32_t)i;
+    radj[atomicAdd(&rcur[c], 1ull)] = (int32_t)i;  // rcur[c] starts at roff[c]: ONE random access per edge
   }
 }
 
 __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __restrict__ hmask,
                                  const int32_t* __restrict__ neigh, const uint8_t* __restrict__ ps,
                                  const int32_t* __restrict__ base, const int64_t* __restrict__ roff,
-                                 const int32_t* __restrict__ radj, int32_t* __restrict__ omega, uint8_t* occ,
+                                 const int32_t* __restrict__ radj, int32_t* __restrict__ omega, uint32_t* occ,
                                  uint8_t* dirty_cur, uint8_t* dirty_next, uint8_t* bdirty_cur, uint8_t* bdirty_next,
                                  int4* rec, int quads, int* any)
 {
@@ -250,15 +252,22 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
     const int64_t e1 = roff[c + 1];
     for (int64_t e = roff[c]; e < e1; e++) {
       const int32_t j = radj[e];
-      if (j < v && __hip_atomic_load(occ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      // occ is a BITMAP (n / 8 bytes: 6 MB at 50 M points, resident in L2 / Infinity Cache), so the ~14
+      // random look-ups per re-evaluated point do not go to HBM
+      if (j < v && ((__hip_atomic_load(occ + (j >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j & 31)) & 1u))
         v = j;
     }
     omega[c] = v;
     reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;  // the growth kernel reads the owner from the record
     const uint32_t m0 = hmask[c];
     const uint8_t want = (m0 != 0 && !ps[c] && v >= (int32_t)c) ? 1 : 0;
-    if (want != occ[c]) {
-      __hip_atomic_store(occ + c, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t cbit = 1u << (c & 31);
+    const uint8_t have = (__hip_atomic_load(occ + (c >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cbit) ? 1 : 0;
+    if (want != have) {
+      if (want)
+        __hip_atomic_fetch_or(occ + (c >> 5), cbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        __hip_atomic_fetch_and(occ + (c >> 5), ~cbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int32_t* row = neigh + c * K;
       uint32_t m = m0;
       while (m) {
@@ -279,7 +288,7 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
 __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ hmask, const uint8_t* __restrict__ ps,
                                        const int32_t* __restrict__ base, const int64_t* __restrict__ roff,
                                        const int32_t* __restrict__ radj, const int32_t* __restrict__ omega,
-                                       const uint8_t* __restrict__ occ, int* nbad)
+                                       const uint32_t* __restrict__ occ, int* nbad)
 {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= n)
@@ -292,7 +301,7 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
       v = j;
   }
   const bool oc = hmask[c] != 0 && !ps[c] && omega[c] >= (int32_t)c;
-  if (v != omega[c] || (oc ? 1 : 0) != occ[c])
+  if (v != omega[c] || (oc ? 1u : 0u) != ((occ[c >> 5] >> (c & 31)) & 1u))
     atomicAdd(nbad, 1);
 }
 
@@ -342,7 +351,7 @@ __device__ inline int32_t* rec_tag(int4* rec, int quads, int64_t i)
 }
 
 template <int KC>
-__global__ void build_records_kernel(SpecArgs a, int4* __restrict__ rec)
+__global__ void build_records_kernel(SpecArgs a, int4* __restrict__ rec, int4* __restrict__ geo)
 {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= a.n)
@@ -354,6 +363,12 @@ __global__ void build_records_kernel(SpecArgs a, int4* __restrict__ rec)
   r[1] = make_int4(__double2loint(nx), __double2hiint(nx), __double2loint(ny), __double2hiint(ny));
   r[2] = make_int4(__double2loint(nz), __double2hiint(nz), INF, 0);
   r[3] = make_int4(0, 0, 0, 0);
+  // position + normal once more as a 64-byte unit: the static-mask pass gathers 15-31 neighbours per point
+  // from random places and needs 36 bytes of each -- half a cache line instead of a line of the record
+  int4* gq = geo + i * 4;
+  gq[0] = r[0];
+  gq[1] = r[1];
+  gq[2] = r[2];
   int row[KC];
 #pragma unroll
   for (int j = 0; j < KC; j++)
@@ -1164,8 +1179,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int32_t* d_seeds = aux + 1024 + 7 * n + 64;  // committed seeds (planes_cap)
   uint8_t* flags = (uint8_t*)(aux + n_i32);
   uint8_t* ps = flags + n;
-  uint8_t* occ = ps + n;
-  uint8_t* dirty0 = occ + n;
+  uint32_t* occ = (uint32_t*)(((uintptr_t)(ps + n) + 15) & ~(uintptr_t)15);  // bitmap, 16-byte aligned: (n + 31) / 32 words
+  uint8_t* dirty0 = (uint8_t*)occ + ((n + 31) / 32) * 4 + 16;
   uint8_t* dirty1 = dirty0 + n;
   uint8_t* bdirty0 = dirty1 + n;  // one flag per 256 points
   uint8_t* bdirty1 = bdirty0 + nb256;
@@ -1192,16 +1207,19 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int quads = 4 + KC / 4;
   BS_HIP(ctx, ctx->rg_rec.reserve(sizeof(int4) * (size_t)quads * n));
   int4* rec = ctx->rg_rec.as<int4>();
+  // setup scratch: 64-byte geometry units (static masks), then reused as the 64-bit fill cursors
+  BS_HIP(ctx, ctx->rg_geo.reserve(sizeof(int4) * 4 * (size_t)n));
+  int4* geo = ctx->rg_geo.as<int4>();
   if (KC == 16)
-    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, rec);
+    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, rec, geo);
   else
-    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec);
+    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec, geo);
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
   // static masks + reverse-list counts in one pass, offsets by a 64-bit exclusive scan over n + 1
   // entries (roff[n] = total), then the fill
   (void)hipEventRecord(ctx->ev[8], st);
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));
-  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, order, rec, quads, hmask, rpos);
+  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, order, rec, geo, quads, hmask, rpos);
   {
     hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*> in(rpos, ToI64());
     size_t tb = 0;
@@ -1209,14 +1227,15 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
     BS_HIP(ctx, hipcub::DeviceScan::ExclusiveScan(ctx->cub_tmp.p, tb, in, roff, hipcub::Sum(), (int64_t)0, (int)(n + 1), st));
   }
-  BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * n, st));
-  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, d_neigh, K, n, order, roff, rpos, radj);
+  unsigned long long* rcur = reinterpret_cast<unsigned long long*>(geo);  // the geometry units are dead by now
+  BS_HIP(ctx, hipMemcpyAsync(rcur, roff, sizeof(int64_t) * n, hipMemcpyDeviceToDevice, st));
+  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, d_neigh, K, n, order, rcur, radj);
   // initial state: no plane, every point dirty, nobody occurs yet (the first pass sets occ)
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, n, INF);
   BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(vmark, 0, sizeof(int32_t) * n, st));
-  BS_HIP(ctx, hipMemsetAsync(occ, 0, n, st));
+  BS_HIP(ctx, hipMemsetAsync(occ, 0, sizeof(uint32_t) * (size_t)((n + 31) / 32), st));
   BS_HIP(ctx, hipMemsetAsync(dirty0, 1, n, st));
   BS_HIP(ctx, hipMemsetAsync(dirty1, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(bdirty0, 1, nb256, st));
