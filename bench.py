@@ -341,7 +341,7 @@ def main():
             out.update({"value": n * args.steps / elapsed / 1e6, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
                         "scaling": "strong",
                         "config": {"workload": args.workload, "points_total": n, "k": k, "rg_mode": args.rg_mode,
-                                   "parallelism": f"stages 1-2: {world} Morton slabs + device halo all-gather (RCCL); "
+                                   "parallelism": f"stages 1-2: {world} Morton slabs, partition + halo by device all-to-all ({args.backend}); "
                                                   "stage 3: replicas only (rank 0 grows, labels broadcast)",
                                    "halo_mm": info.get("halo"), "halo_retries": info.get("retries"),
                                    "n_local_rank0": info.get("n_local")},

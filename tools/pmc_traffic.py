@@ -6,7 +6,8 @@ one TCC pass) of `bench.py` into profiles/pmc_traffic.json.
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <n_segment_calls> <workload> > profiles/pmc_traffic.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <n_segment_calls> <workload> [profiles/pmc_traffic.json] > new.json
+(the JSON is keyed by workload; an existing file given as 5th argument is updated)
 
 gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B, i.e. reports half of
 the bytes of wide reads -> HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (counters are in KB).
@@ -34,10 +35,13 @@ def per_kernel(d):
 def main():
     fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
     calls = int(sys.argv[3])
-    stage3 = ["grow_spec_kernel", "pull_pass_kernel", "static_mask_kernel", "rev_count_kernel", "rev_fill_kernel",
-              "refresh_records_kernel", "build_records_kernel", "validate1_kernel", "validate2_kernel",
-              "plane_apply_kernel", "cand_flag_kernel", "copy_lists_kernel", "label_kernel", "fill_i32_kernel"]
-    out = {"workload": sys.argv[4], "segment_calls_in_run": calls,
+    workload = sys.argv[4]
+    merge_into = sys.argv[5] if len(sys.argv) > 5 else None  # existing per-workload JSON to update
+    stage3 = ["grow_spec_kernel", "pull_pass_kernel", "static_mask_kernel", "rev_fill_kernel",
+              "refresh_records_kernel", "build_records_kernel", "validate1_kernel", "validate2_kernel", "validate3_kernel",
+              "plane_apply_kernel", "cand_flag_kernel", "copy_lists_kernel", "label_kernel", "fill_i32_kernel",
+              "reset_tags_kernel"]
+    out = {"workload": workload, "segment_calls_in_run": calls,
            "formula": "2*FETCH_SIZE + WRITE_SIZE (KB counters), per bs_segment_dev call", "kernels": {}}
     tot = 0.0
     for k in sorted(set(fetch) | set(write)):
@@ -49,7 +53,16 @@ def main():
     out["region_grow_stage_bytes_per_call"] = tot
     out["grow_spec_kernel_bytes_per_call"] = out["kernels"].get("grow_spec_kernel", {}).get("hbm_bytes")
     out["knn_fast_kernel_bytes_per_call"] = out["kernels"].get("knn_fast_kernel", {}).get("hbm_bytes")
-    print(json.dumps(out, indent=1))
+    db = {}
+    if merge_into:
+        try:
+            db = json.load(open(merge_into))
+            if "workload" in db:  # round-1 single-workload layout
+                db = {db["workload"]: db}
+        except (OSError, ValueError):
+            db = {}
+    db[workload] = out
+    print(json.dumps(db, indent=1))
 
 
 if __name__ == "__main__":
