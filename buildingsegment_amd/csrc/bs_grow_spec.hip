@@ -36,6 +36,17 @@
 //
 // Final labels: plane_idx[p] = 1 + #(committed planes with seed < owner[p])
 // (cur_planeId only advances on commit, :199-202), -1 if owner[p] is none.
+//
+// Index spaces.  Everything in this file ADDRESSES points by their position in the search grid's
+// cell-sorted (Morton) order -- records, masks, owners, reverse lists, neighbour rows, plane lists
+// during growth -- so that the neighbours of a point live in nearby memory and the graph passes
+// (static masks, reverse lists, owner fixed point, candidate scan) are served by L2 instead of
+// one HBM access per edge.  The sequential semantics of the reference are about the ORIGINAL
+// indices (seed scan order :184, "earlier attempt wins"): prio[s] = original index of position s is
+// the PRIORITY, and every value that is compared -- seeds, owners, claim tags, F -- is an original
+// index.  Positions never take part in a comparison; original indices never address anything but
+// dead[] (per-seed flags) and the caller's output arrays.  Without a cached grid order (foreign
+// input handed to bs_region_grow*) the order is the identity.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -78,13 +89,13 @@ struct PlaneOut {
   int64_t log_n;
   int64_t steps;
   int32_t center[3];
-  int32_t seed;
+  int32_t seed;        // original index of the seed
   int32_t status;
   int32_t keep;        // committed (list_n > th_count)
   int32_t consistent;  // set by validate2_kernel
   int32_t pad;         // host command for plane_apply_kernel
   int32_t thief;       // diagnostics: seed of the plane that took a point from this one (-1: none)
-  int32_t pad2;
+  int32_t seed_pos;    // position of the seed (seed itself is the ORIGINAL index: the priority)
 };
 
 struct Pool {
@@ -156,14 +167,12 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
 // order (nullable): a spatially coherent permutation (the grid's cell-sorted
 // order), so that the neighbour gathers of adjacent threads share cache lines.
 // Neighbour geometry comes from the one-line-per-point records.
-__global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order, const int4* __restrict__ rec,
-                                   const int4* __restrict__ geo, int quads, uint32_t* __restrict__ hmask,
-                                   int32_t* __restrict__ rcnt)
+__global__ void static_mask_kernel(SpecArgs a, const int4* __restrict__ rec, int quads,
+                                   uint32_t* __restrict__ hmask, int32_t* __restrict__ rcnt)
 {
-  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
-  if (s >= a.n)
+  const int64_t i = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;  // position: spatial neighbours are adjacent threads
+  if (i >= a.n)
     return;
-  const int64_t i = order ? order[s] : s;
   const int4* ri = rec + i * quads;
   const int4 s0 = ri[0], s1 = ri[1], s2 = ri[2];
   const double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z),
@@ -172,7 +181,7 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
   const int32_t* row = reinterpret_cast<const int32_t*>(ri + 4);
   uint32_t m = 0;
   for (int t = 1; t < a.K; t++) {
-    const int4* rc = geo + (int64_t)row[t] * 4;
+    const int4* rc = rec + (int64_t)row[t] * quads;
     const int4 q0 = rc[0], q1 = rc[1];
     const int2 q2 = *reinterpret_cast<const int2*>(rc + 2);
     const int dx = (int)((uint32_t)q0.x - (uint32_t)ccx);
@@ -197,16 +206,14 @@ __global__ void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ order
 // points until nothing flips.  Dependencies only run from lower to higher
 // indices, so the iteration settles bottom-up to the unique fixed point; work is
 // proportional to what actually changes, not to n.
-__global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                int64_t n, const int32_t* __restrict__ order, unsigned long long* __restrict__ rcur,
-                                int32_t* __restrict__ radj)
+__global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec, int quads, int64_t n,
+                                unsigned long long* __restrict__ rcur, int32_t* __restrict__ radj)
 {
-  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
-  if (s >= n)
+  const int64_t i = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n)
     return;
-  const int64_t i = order ? order[s] : s;
   uint32_t m = hmask[i];
-  const int32_t* row = neigh + i * K;
+  const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
   while (m) {
     const int t = __ffs(m) - 1;
     m &= m - 1;
@@ -216,7 +223,7 @@ __global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_
 }
 
 __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __restrict__ hmask,
-                                 const int32_t* __restrict__ neigh, const uint8_t* __restrict__ ps,
+                                 const int32_t* __restrict__ prio, const uint8_t* __restrict__ ps,
                                  const int32_t* __restrict__ base, const int64_t* __restrict__ roff,
                                  const int32_t* __restrict__ radj, int32_t* __restrict__ omega, uint32_t* occ,
                                  uint8_t* dirty_cur, uint8_t* dirty_next, uint8_t* bdirty_cur, uint8_t* bdirty_next,
@@ -254,13 +261,15 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
       const int32_t j = radj[e];
       // occ is a BITMAP (n / 8 bytes: 6 MB at 50 M points, resident in L2 / Infinity Cache), so the ~14
       // random look-ups per re-evaluated point do not go to HBM
-      if (j < v && ((__hip_atomic_load(occ + (j >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j & 31)) & 1u))
-        v = j;
+      if ((__hip_atomic_load(occ + (j >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j & 31)) & 1u) {
+        const int32_t pj = prio[j];  // makers are compared by ORIGINAL index
+        v = pj < v ? pj : v;
+      }
     }
     omega[c] = v;
     reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;  // the growth kernel reads the owner from the record
     const uint32_t m0 = hmask[c];
-    const uint8_t want = (m0 != 0 && !ps[c] && v >= (int32_t)c) ? 1 : 0;
+    const uint8_t want = (m0 != 0 && !ps[c] && v >= prio[c]) ? 1 : 0;
     const uint32_t cbit = 1u << (c & 31);
     const uint8_t have = (__hip_atomic_load(occ + (c >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cbit) ? 1 : 0;
     if (want != have) {
@@ -268,7 +277,7 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
         __hip_atomic_fetch_or(occ + (c >> 5), cbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else
         __hip_atomic_fetch_and(occ + (c >> 5), ~cbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int32_t* row = neigh + c * K;
+      const int32_t* row = reinterpret_cast<const int32_t*>(rec + c * quads + 4);
       uint32_t m = m0;
       while (m) {
         const int b = __ffs(m) - 1;
@@ -285,7 +294,8 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
 }
 
 // BS_VERIFY=1: is (omega, occ) a fixed point of the owner equations?
-__global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ hmask, const uint8_t* __restrict__ ps,
+__global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ hmask, const int32_t* __restrict__ prio,
+                                       const uint8_t* __restrict__ ps,
                                        const int32_t* __restrict__ base, const int64_t* __restrict__ roff,
                                        const int32_t* __restrict__ radj, const int32_t* __restrict__ omega,
                                        const uint32_t* __restrict__ occ, int* nbad)
@@ -296,38 +306,37 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
   int32_t v = base[c];
   for (int64_t e = roff[c]; e < roff[c + 1]; e++) {
     const int32_t j = radj[e];
-    const bool oj = hmask[j] != 0 && !ps[j] && omega[j] >= j;
-    if (oj && j < v)
-      v = j;
+    const bool oj = hmask[j] != 0 && !ps[j] && omega[j] >= prio[j];
+    if (oj && prio[j] < v)
+      v = prio[j];
   }
-  const bool oc = hmask[c] != 0 && !ps[c] && omega[c] >= (int32_t)c;
+  const bool oc = hmask[c] != 0 && !ps[c] && omega[c] >= prio[c];
   if (v != omega[c] || (oc ? 1u : 0u) != ((occ[c >> 5] >> (c & 31)) & 1u))
     atomicAdd(nbad, 1);
 }
 
 // ---- plane-attempt candidates -------------------------------------------------
-__global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ neigh, int K,
-                                 int64_t n, int32_t F, const uint8_t* __restrict__ ps,
-                                 const int32_t* __restrict__ omega, uint8_t* __restrict__ flags, int32_t* min_idx,
-                                 int32_t* __restrict__ cand_out, int32_t* cand_count)
+__global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec, int quads, int K,
+                                 int64_t n, int32_t F, const int32_t* __restrict__ prio, const uint8_t* __restrict__ ps,
+                                 const int32_t* __restrict__ omega, int32_t* min_idx,
+                                 unsigned long long* __restrict__ cand_out, int32_t* cand_count)
 {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n)
     return;
   bool c = false;
   const uint32_t full = (K - 1 >= 32) ? 0xffffffffu : ((1u << (K - 1)) - 1u);
-  if (i >= F && !ps[i] && hmask[i] == full && omega[i] >= (int32_t)i) {
+  const int32_t pi = prio[i];
+  if (pi >= F && !ps[i] && hmask[i] == full && omega[i] >= pi) {
     c = true;
-    const int32_t* row = neigh + i * K;
+    const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
     for (int t = 1; t < K; t++)
-      c = c && omega[row[t]] >= (int32_t)i;
+      c = c && omega[row[t]] >= pi;
   }
-  if (flags)
-    flags[i] = c ? 1 : 0;
   if (c && min_idx)
-    atomicMin(min_idx, (int32_t)i);
-  if (c && cand_out)  // candidates are sparse: appended unordered, the (few) entries are sorted afterwards
-    cand_out[atomicAdd(cand_count, 1)] = (int32_t)i;
+    atomicMin(min_idx, pi);
+  if (c && cand_out)  // sparse: appended unordered as (original index << 32 | position), sorted afterwards
+    cand_out[atomicAdd(cand_count, 1)] = ((unsigned long long)(uint32_t)pi << 32) | (uint32_t)i;
 }
 
 // ---- (b) speculative plane growth: one wavefront per candidate seed -------------
@@ -350,29 +359,42 @@ __device__ inline int32_t* rec_tag(int4* rec, int quads, int64_t i)
   return reinterpret_cast<int32_t*>(rec + i * quads + 2) + 2;
 }
 
-template <int KC>
-__global__ void build_records_kernel(SpecArgs a, int4* __restrict__ rec, int4* __restrict__ geo)
+__global__ void invert_order_kernel(const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ pos)
 {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= a.n)
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s < n)
+    pos[order[s]] = (int32_t)s;
+}
+
+// One record per POSITION s of the cell-sorted order (order[s] = original index, pos = its inverse;
+// both null: identity).  The neighbour row is translated to positions here -- the one pass of the
+// stage that has to look things up by original index.
+template <int KC>
+__global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ order, const int32_t* __restrict__ pos,
+                                     int4* __restrict__ rec, int32_t* __restrict__ prio)
+{
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= a.n)
     return;
   constexpr int Q = RecLayout<KC>::QUADS;
-  int4* r = rec + i * Q;
+  const int64_t i = order ? order[s] : s;
+  int4* r = rec + s * Q;
   const double nx = a.normals[3 * i], ny = a.normals[3 * i + 1], nz = a.normals[3 * i + 2];
   r[0] = make_int4(a.xyz[3 * i], a.xyz[3 * i + 1], a.xyz[3 * i + 2], INF);
   r[1] = make_int4(__double2loint(nx), __double2hiint(nx), __double2loint(ny), __double2hiint(ny));
   r[2] = make_int4(__double2loint(nz), __double2hiint(nz), INF, 0);
   r[3] = make_int4(0, 0, 0, 0);
-  // position + normal once more as a 64-byte unit: the static-mask pass gathers 15-31 neighbours per point
-  // from random places and needs 36 bytes of each -- half a cache line instead of a line of the record
-  int4* gq = geo + i * 4;
-  gq[0] = r[0];
-  gq[1] = r[1];
-  gq[2] = r[2];
+  prio[s] = (int32_t)i;
   int row[KC];
 #pragma unroll
-  for (int j = 0; j < KC; j++)
-    row[j] = j < a.K ? a.neigh[i * a.K + j] : 0;
+  for (int j = 0; j < KC; j++) {
+    int v = 0;
+    if (j < a.K) {
+      v = a.neigh[i * a.K + j];
+      v = pos ? pos[v] : v;
+    }
+    row[j] = v;
+  }
 #pragma unroll
   for (int j = 0; j < KC; j += 4)
     r[4 + j / 4] = make_int4(row[j], row[j + 1], row[j + 2], row[j + 3]);
@@ -412,7 +434,7 @@ constexpr int RETRY_MAX_LIST = 16384;  // ... as long as little work is thrown a
 //    non-empty one and leaves the rest on the LIFO.  Claims (atomics) are only
 //    issued for the call that is really expanded.
 template <int KC>
-__global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t* __restrict__ cand, int ncand,
+__global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigned long long* __restrict__ cand, int ncand,
                                                        int4* rec, int32_t* dead, Pool pool,
                                                        PlaneOut* __restrict__ out, int64_t step_cap, int retry_max_list)
 {
@@ -427,7 +449,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   const unsigned long long gmask0 = (KC == 32) ? 0xffffffffull : 0xffffull;
   const int K = a.K, nc = K - 1;
   const bool act = j < nc;
-  const int32_t seed = cand[w];
+  const int32_t seed = (int32_t)(cand[w] >> 32);         // original index: what claims and owners are compared by
+  const int32_t seed_s = (int32_t)(uint32_t)cand[w];     // position: where the seed's record lives
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
   // 32-bit bookkeeping (n < 2^31): 64-bit scalar arithmetic doubles the SALU work of every call
   int ln = 1, sp = 0, lds_lo = 0, logn = 0;
@@ -448,7 +471,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
   bool pendv = false;
   const int32_t* vptr = dead;  // tag word claimed by the previous call (any valid address while !pendv)
   bool need_state = false;
-  const int4* srec = rec + (int64_t)seed * Q;
+  const int4* srec = rec + (int64_t)seed_s * Q;
   const int4 s0 = srec[0], s1 = srec[1], s2 = srec[2];
   double cnx, cny, cnz, Sx, Sy, Sz;
   int ccx, ccy, ccz;
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     status = ST_NOMEM;
   } else {
     if (lane == 0)
-      pool.base[list.off] = seed;
+      pool.base[list.off] = seed_s;  // lists hold positions until they are committed
     // every pending call is a LIFO entry (id + row) in the LDS window; at the start
     // the only entry is Broad(seed, 0)
     if (lane < KC)
@@ -813,7 +836,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const int32_t
     o.pad = 0;
     const int dflag = ld_i32(dead + seed);
     o.thief = (dflag < 0 ? -dflag : dflag) - 1;
-    o.pad2 = 0;
+    o.seed_pos = seed_s;
     out[w] = o;
   }
 }
@@ -1004,9 +1027,9 @@ __global__ __launch_bounds__(VT) void plane_apply_kernel(const PlaneOut* __restr
     return;
   const bool ins = o.pad == 1;
   if (threadIdx.x == 0) {
-    ps[o.seed] = ins ? 1 : 0;
-    dirty[o.seed] = 1;
-    bdirty[o.seed >> 8] = 1;
+    ps[o.seed_pos] = ins ? 1 : 0;
+    dirty[o.seed_pos] = 1;
+    bdirty[o.seed_pos >> 8] = 1;
   }
   if (!o.keep)
     return;
@@ -1026,8 +1049,7 @@ __global__ __launch_bounds__(VT) void plane_apply_kernel(const PlaneOut* __restr
 // 0 -- neighbours of the seed that were claimed in the very step that failed and
 // never reached the list.  Replaces a full pass over all records per round.
 __global__ __launch_bounds__(VT) void reset_tags_kernel(const PlaneOut* __restrict__ out, int ncand,
-                                                        const int32_t* __restrict__ pool, int4* rec, int quads,
-                                                        const int32_t* __restrict__ neigh, int K)
+                                                        const int32_t* __restrict__ pool, int4* rec, int quads, int K)
 {
   const int w = blockIdx.x;
   if (w >= ncand)
@@ -1039,7 +1061,7 @@ __global__ __launch_bounds__(VT) void reset_tags_kernel(const PlaneOut* __restri
       *tg = INF;
   }
   if (threadIdx.x >= 1 && threadIdx.x < K) {
-    int32_t* tg = rec_tag(rec, quads, neigh[(int64_t)o.seed * K + threadIdx.x]);
+    int32_t* tg = rec_tag(rec, quads, reinterpret_cast<const int32_t*>(rec + (int64_t)o.seed_pos * quads + 4)[threadIdx.x]);
     if (*tg == o.seed)
       *tg = INF;
   }
@@ -1056,8 +1078,8 @@ __global__ void verify_records_kernel(const int32_t* __restrict__ omega, int4* r
 }
 
 __global__ __launch_bounds__(VT) void validate2_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
-                                                       const int32_t* __restrict__ omega,
-                                                       const int32_t* __restrict__ neigh, int K)
+                                                       const int32_t* __restrict__ omega, const int4* __restrict__ rec,
+                                                       int quads, int K)
 {
   const int w = blockIdx.x;
   if (w >= ncand || out[w].status != ST_DONE)
@@ -1066,9 +1088,9 @@ __global__ __launch_bounds__(VT) void validate2_kernel(PlaneOut* out, int ncand,
   const int32_t s = o.seed;
   bool bad = false;
   if (threadIdx.x == 0)
-    bad = omega[s] < s;  // (1) the seed is still free at its time ...
-  if (threadIdx.x >= 1 && threadIdx.x < K)
-    bad = omega[neigh[(int64_t)s * K + threadIdx.x]] < s;  // ... and so are its K-1 neighbours
+    bad = omega[o.seed_pos] < s;  // (1) the seed is still free at its time ...
+  if (threadIdx.x >= 1 && threadIdx.x < K)  // ... and so are its K-1 neighbours
+    bad = omega[reinterpret_cast<const int32_t*>(rec + (int64_t)o.seed_pos * quads + 4)[threadIdx.x]] < s;
   for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT)  // (2) accepted points were free
     bad = bad || omega[pool[o.list_off + t]] < s;
   for (int64_t t = threadIdx.x; t < o.log_n; t += VT)  // (3) assumed-taken points are taken
@@ -1082,6 +1104,7 @@ struct CopyDesc {
   const int32_t* src;
   int32_t* dst;
   int64_t cnt;
+  const int32_t* map;  // committed lists leave position space: dst = map[src] (null: plain copy)
 };
 
 __global__ void copy_lists_kernel(const CopyDesc* __restrict__ d, int nd)
@@ -1091,18 +1114,19 @@ __global__ void copy_lists_kernel(const CopyDesc* __restrict__ d, int nd)
     return;
   const CopyDesc c = d[w];
   for (int64_t i = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; i < c.cnt; i += (int64_t)gridDim.y * blockDim.x)
-    c.dst[i] = c.src[i];
+    c.dst[i] = c.map ? c.map[c.src[i]] : c.src[i];
 }
 
 __global__ void label_kernel(const int32_t* __restrict__ owner, int64_t n, const int32_t* __restrict__ seeds,
-                             int np, int32_t* __restrict__ plane_idx)
+                             int np, const int32_t* __restrict__ prio, int32_t* __restrict__ plane_idx)
 {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n)
     return;
   const int32_t o = owner[i];
+  const int64_t dst = prio[i];  // i is a position; the caller's label array is in original order
   if (o == INF) {
-    plane_idx[i] = -1;
+    plane_idx[dst] = -1;
     return;
   }
   int lo = 0, hi = np;  // number of committed seeds < o
@@ -1113,7 +1137,7 @@ __global__ void label_kernel(const int32_t* __restrict__ owner, int64_t n, const
     else
       hi = mid;
   }
-  plane_idx[i] = 1 + lo;
+  plane_idx[dst] = 1 + lo;
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
@@ -1155,7 +1179,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   BS_HIP(ctx, ctx->rg_list.reserve(sizeof(int32_t) * list_cap));
   BS_HIP(ctx, ctx->rg_planes.reserve(sizeof(PlaneRec) * planes_cap));
   BS_HIP(ctx, ctx->rg_stats.reserve(sizeof(GrowStats)));
-  // aux layout (int32 units): misc[1024] | hmask | omega | base | dead | cand | roff(n+2) | rpos | seeds |
+  // aux layout (int32 units): misc[1024] | hmask | omega | base | dead | prio | rpos(n+64) | vmark | seeds |
   //                            (u8) flags | ps | occ | dirty0 | dirty1 | PlaneOut[MAX_WAVES + MAX_PENDING] | CopyDesc[]
   const size_t n_i32 = (size_t)(7 * n + planes_cap + 1024 + 128);
   const size_t nb256 = (size_t)((n + 255) / 256);
@@ -1173,7 +1197,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int32_t* omega = aux + 1024 + n;
   int32_t* base = aux + 1024 + 2 * n;
   int32_t* dead = aux + 1024 + 3 * n;
-  int32_t* d_cand = aux + 1024 + 4 * n;  // select output (n entries)
+  int32_t* prio = aux + 1024 + 4 * n;    // original index of every position (n entries)
   int32_t* rpos = aux + 1024 + 5 * n;    // n + 1 (+ pad): reverse-list counts / fill cursors, later the candidate scratch
   int32_t* vmark = aux + 1024 + 6 * n + 64;    // duplicate detection of validate1 (n entries)
   int32_t* d_seeds = aux + 1024 + 7 * n + 64;  // committed seeds (planes_cap)
@@ -1207,19 +1231,27 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int quads = 4 + KC / 4;
   BS_HIP(ctx, ctx->rg_rec.reserve(sizeof(int4) * (size_t)quads * n));
   int4* rec = ctx->rg_rec.as<int4>();
-  // setup scratch: 64-byte geometry units (static masks), then reused as the 64-bit fill cursors
-  BS_HIP(ctx, ctx->rg_geo.reserve(sizeof(int4) * 4 * (size_t)n));
-  int4* geo = ctx->rg_geo.as<int4>();
-  if (KC == 16)
-    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, rec, geo);
-  else
-    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, rec, geo);
+  // scratch: the 64-bit fill cursors of the reverse lists during setup, then the candidate lists
+  // (unsorted | sorted, one (original index << 32 | position) key each)
+  BS_HIP(ctx, ctx->rg_geo.reserve(sizeof(unsigned long long) * 2 * (size_t)(n + 64)));
+  unsigned long long* cand_raw = ctx->rg_geo.as<unsigned long long>();
+  unsigned long long* d_cand = cand_raw + n + 64;
+  // positions = the search grid's cell-sorted (Morton) order of THIS cloud when it is cached on the context
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
+  int32_t* pos = nullptr;
+  (void)hipEventRecord(ctx->ev[8], st);
+  if (order) {
+    pos = vmark;  // (free until the validation marks are cleared below)
+    invert_order_kernel<<<nblk(n, 256), 256, 0, st>>>(order, n, pos);
+  }
+  if (KC == 16)
+    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, rec, prio);
+  else
+    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, rec, prio);
   // static masks + reverse-list counts in one pass, offsets by a 64-bit exclusive scan over n + 1
   // entries (roff[n] = total), then the fill
-  (void)hipEventRecord(ctx->ev[8], st);
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));
-  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, order, rec, geo, quads, hmask, rpos);
+  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, rec, quads, hmask, rpos);
   {
     hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*> in(rpos, ToI64());
     size_t tb = 0;
@@ -1227,9 +1259,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
     BS_HIP(ctx, hipcub::DeviceScan::ExclusiveScan(ctx->cub_tmp.p, tb, in, roff, hipcub::Sum(), (int64_t)0, (int)(n + 1), st));
   }
-  unsigned long long* rcur = reinterpret_cast<unsigned long long*>(geo);  // the geometry units are dead by now
+  unsigned long long* rcur = cand_raw;
   BS_HIP(ctx, hipMemcpyAsync(rcur, roff, sizeof(int64_t) * n, hipMemcpyDeviceToDevice, st));
-  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, d_neigh, K, n, order, rcur, radj);
+  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rec, quads, n, rcur, radj);
   // initial state: no plane, every point dirty, nobody occurs yet (the first pass sets occ)
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, n, INF);
@@ -1251,7 +1283,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   auto propagate = [&]() -> int {
     for (int it = 0; it < 1000000; it++) {
       BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
-      pull_pass_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(n, K, pull_sub, hmask, d_neigh, ps, base, roff, radj,
+      pull_pass_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(n, K, pull_sub, hmask, prio, ps, base, roff, radj,
                                                                                 omega, occ, dcur, dnext, bcur, bnext, rec, quads,
                                                                                 d_misc);
       int any = 0;
@@ -1263,7 +1295,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       if (!any) {
         if (getenv("BS_VERIFY")) {
           BS_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, sizeof(int), st));
-          verify_fixpoint_kernel<<<nblk(n, 256), 256, 0, st>>>(n, hmask, ps, base, roff, radj, omega, occ, d_misc + 3);
+          verify_fixpoint_kernel<<<nblk(n, 256), 256, 0, st>>>(n, hmask, prio, ps, base, roff, radj, omega, occ, d_misc + 3);
           int nb = 0;
           BS_HIP(ctx, hipMemcpyAsync(&nb, d_misc + 3, sizeof nb, hipMemcpyDeviceToHost, st));
           BS_HIP(ctx, hipStreamSynchronize(st));
@@ -1299,18 +1331,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const bool force_full_refresh = getenv("BS_FULL_REFRESH") != nullptr;  // debugging aid: the pre-incremental behaviour
   bool full_refresh = force_full_refresh;
   int32_t F = 0;
-  size_t sel_tmp = 0;
-  {
-    BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, sel_tmp, rpos, d_cand, (int)n, 0, 32, st));
-    BS_HIP(ctx, ctx->cub_tmp.reserve(sel_tmp));
-  }
   auto commit_plane = [&](const PlaneOut& o, const int32_t* src_pool) -> int {
     attempts++;
     if (!o.keep)
       return BS_OK;  // rolled back: no trace
     if (list_used + o.list_n > list_cap || (int64_t)recs.size() >= planes_cap)
       return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): list pool overflow");
-    copies.push_back({src_pool + o.list_off, ctx->rg_list.as<int32_t>() + list_used, o.list_n});
+    copies.push_back({src_pool + o.list_off, ctx->rg_list.as<int32_t>() + list_used, o.list_n, prio});
     PlaneRec r;
     for (int c = 0; c < 3; c++) {
       r.normal[c] = o.normal[c];
@@ -1358,7 +1385,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // lowest NEW candidate sees exactly the owners this round starts from unless planes were dropped)
     if (!cand_listed) {
       BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
-      cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, nullptr, rpos, d_misc + 1);
+      cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, nullptr, cand_raw, d_misc + 1);
       BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
     }
@@ -1366,8 +1393,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     if (ncand_all == 0 && npend == 0)
       break;  // no plane attempt left: omega is the final owner array
     if (ncand_all > 0) {
-      size_t tb = sel_tmp;
-      BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tb, rpos, d_cand, ncand_all, 0, 32, st));
+      size_t tb = 0;
+      BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, cand_raw, d_cand, ncand_all, 0, 64, st));
+      BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
+      BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tb, cand_raw, d_cand, ncand_all, 0, 64, st));
     }
     const int ncand = std::min<int>(ncand_all, max_waves);
     if (npend)
@@ -1408,21 +1437,21 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
                                              (int32_t)((rounds & 0x3fff) << 17), d_misc + 4);
       if (do_validate3)
         validate3_kernel<<<ncand, V3T, 0, st>>>(d_out, ncand, pool.base, rec, quads, d_misc + 4);
-      reset_tags_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, d_neigh, K);
+      reset_tags_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, K);
       // insert the finished planes and let the owners settle
       plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur);
       rc = propagate();
       if (rc != BS_OK)
         return rc;
-      validate2_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, omega, d_neigh, K);
+      validate2_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, omega, rec, quads, K);
     }
     if (npend)
-      validate2_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, omega, d_neigh, K);
+      validate2_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, omega, rec, quads, K);
     // lowest candidate under the new owners (= first attempt that is not established yet) and, in the
     // same pass, the candidate list of the next round
     const int32_t init2[2] = {0, INF};
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 1, init2, sizeof init2, hipMemcpyHostToDevice, st));
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, d_neigh, K, n, F, ps, omega, nullptr, d_misc + 2, rpos, d_misc + 1);
+    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, d_misc + 2, cand_raw, d_misc + 1);
     int32_t new_min = INF, next_ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipMemcpyAsync(&next_ncand_all, d_misc + 1, sizeof next_ncand_all, hipMemcpyDeviceToHost, st));
@@ -1527,11 +1556,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
           pend_room--;
           PlaneOut q = o;
           q.list_off = pstore_top;
-          copies.push_back({pool.base + o.list_off, pstore + q.list_off, o.list_n});
+          copies.push_back({pool.base + o.list_off, pstore + q.list_off, o.list_n, nullptr});
           pstore_top += (o.list_n + 3) & ~(int64_t)3;
           q.log_off = pstore_top;
           if (o.log_n)
-            copies.push_back({pool.base + o.log_off, pstore + q.log_off, o.log_n});
+            copies.push_back({pool.base + o.log_off, pstore + q.log_off, o.log_n, nullptr});
           pstore_top += (o.log_n + 3) & ~(int64_t)3;
           next_pending.push_back(q);
         } else {
@@ -1582,7 +1611,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, hipMemcpyAsync(d_seeds, seeds.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
     BS_HIP(ctx, hipMemcpyAsync(ctx->rg_planes.p, recs.data(), sizeof(PlaneRec) * np, hipMemcpyHostToDevice, st));
   }
-  label_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, d_seeds, np, d_plane_idx);
+  label_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, d_seeds, np, prio, d_plane_idx);
   int32_t vstat[3] = {0, 0, 0};
   BS_HIP(ctx, hipMemcpyAsync(vstat, d_misc + 4, sizeof vstat, hipMemcpyDeviceToHost, st));
   GrowStats hs;
