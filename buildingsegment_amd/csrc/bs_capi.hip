@@ -182,7 +182,7 @@ void bs_destroy(bs_ctx* c)
   bs::DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->cub_tmp, &c->uniq_keys,
                         &c->uniq_cnt, &c->misc, &c->table, &c->spts, &c->slocal, &c->fb_list, &c->d_xyz_h,
                         &c->d_neigh_h, &c->d_normals_h, &c->d_plane_h, &c->seg_neigh, &c->seg_normals,
-                        &c->rg_list, &c->rg_stack, &c->rg_planes, &c->rg_stats, &c->rg_aux, &c->rg_pstore, &c->rg_rec, &c->rg_radj, &c->rg_roff, &c->rg_geo,
+                        &c->rg_list, &c->rg_stack, &c->rg_planes, &c->rg_stats, &c->rg_aux, &c->rg_pstore, &c->rg_rec, &c->rg_radj, &c->rg_roff, &c->rg_geo, &c->seg_npos,
                         &c->rs_keys_in, &c->rs_keys_out, &c->rs_vals_in, &c->rs_vals_out, &c->rs_cnt, &c->rs_img, &c->rs_tmp};
   for (auto* b : bufs)
     b->release();
@@ -216,9 +216,9 @@ int bs_get_timings(const bs_ctx* ctx, bs_timings* out)
 // device-buffer entry points
 // ---------------------------------------------------------------------------
 
-int bs_knn_normals_dev(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t n, int64_t q_begin,
-                       int64_t q_end, const bs_params* p, int32_t* d_neigh, double* d_normals,
-                       double cert_radius, int64_t* n_uncertified)
+static int knn_normals_dev_impl(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t n, int64_t q_begin,
+                                int64_t q_end, const bs_params* p, int32_t* d_neigh, double* d_normals,
+                                double cert_radius, int64_t* n_uncertified, int32_t* d_npos)
 {
   if (!ctx)
     return BS_ERR_INVALID;
@@ -237,7 +237,8 @@ int bs_knn_normals_dev(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx,
   if (rc != BS_OK)
     return rc;
   T.mark(1);
-  rc = launch_knn_normals(ctx, g, q_begin, q_end, *p, d_neigh, d_normals, cert_radius, n_uncertified);
+  ctx->npos_neigh = nullptr;
+  rc = launch_knn_normals(ctx, g, q_begin, q_end, *p, d_neigh, d_normals, cert_radius, n_uncertified, d_npos);
   if (rc != BS_OK)
     return rc;
   T.mark(2);
@@ -245,7 +246,19 @@ int bs_knn_normals_dev(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx,
   ctx->tm.grid_ms = T.ms(0, 1);
   ctx->tm.knn_ms = T.ms(1, 2);
   ctx->tm.total_ms = T.ms(0, 2);
+  if (d_npos) {  // valid for exactly this neighbour buffer / k (checked by the grower)
+    ctx->npos_neigh = d_neigh;
+    ctx->npos_k = p->k;
+  }
   return BS_OK;
+}
+
+int bs_knn_normals_dev(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t n, int64_t q_begin,
+                       int64_t q_end, const bs_params* p, int32_t* d_neigh, double* d_normals,
+                       double cert_radius, int64_t* n_uncertified)
+{
+  return knn_normals_dev_impl(ctx, d_xyz, d_gidx, n, q_begin, q_end, p, d_neigh, d_normals, cert_radius, n_uncertified,
+                              nullptr);
 }
 
 int bs_region_grow_dev(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
@@ -275,7 +288,13 @@ int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params
   }
   EventTimer T(ctx);
   T.mark(5);
-  rc = bs_knn_normals_dev(ctx, d_xyz, nullptr, n, 0, n, p, d_neigh, d_normals, 0.0, nullptr);
+  // the fused pipeline also keeps every neighbour's cell-sorted position for the grower (speculative mode)
+  int32_t* d_npos = nullptr;
+  if (p->rg_mode != 1) {
+    BS_HIP(ctx, ctx->seg_npos.reserve(sizeof(int32_t) * (size_t)n * p->k));
+    d_npos = ctx->seg_npos.as<int32_t>();
+  }
+  rc = knn_normals_dev_impl(ctx, d_xyz, nullptr, n, 0, n, p, d_neigh, d_normals, 0.0, nullptr, d_npos);
   if (rc != BS_OK)
     return rc;
   rc = region_grow_dev_impl(ctx, d_xyz, d_normals, d_neigh, n, p, d_plane_idx, true);  // our own k-lists: in range

@@ -132,6 +132,11 @@ struct bs_ctx {
   // cell-sorted order of the last grid build (vals_out): spatially coherent iteration for gathers
   int64_t order_n = 0;
   const int32_t* order_xyz = nullptr;
+  // neighbour rows as cell-sorted POSITIONS (rows in position order), written by the kNN kernels of the fused
+  // pipeline for the same cloud / k / neigh buffer: the grower takes them instead of translating indices
+  bs::DevBuf seg_npos;
+  const int32_t* npos_neigh = nullptr;
+  int npos_k = 0;
 };
 
 namespace bs {
@@ -151,7 +156,7 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
 // knn.hip
 int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q_end,
                        const bs_params& p, int32_t* d_neigh, double* d_normals, double cert_radius,
-                       int64_t* n_uncertified);
+                       int64_t* n_uncertified, int32_t* d_npos = nullptr);
 // grow.hip
 int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals,
                            const int32_t* d_neigh, int64_t n, const bs_params& p,

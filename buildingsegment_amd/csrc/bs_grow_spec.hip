@@ -371,7 +371,7 @@ __global__ void invert_order_kernel(const int32_t* __restrict__ order, int64_t n
 // stage that has to look things up by original index.
 template <int KC>
 __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ order, const int32_t* __restrict__ pos,
-                                     int4* __restrict__ rec, int32_t* __restrict__ prio)
+                                     const int32_t* __restrict__ npos, int4* __restrict__ rec, int32_t* __restrict__ prio)
 {
   const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s >= a.n)
@@ -390,8 +390,12 @@ __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ ord
   for (int j = 0; j < KC; j++) {
     int v = 0;
     if (j < a.K) {
-      v = a.neigh[i * a.K + j];
-      v = pos ? pos[v] : v;
+      if (npos) {  // positions straight from the kNN kernels (rows in position order: coalesced)
+        v = npos[s * a.K + j];
+      } else {
+        v = a.neigh[i * a.K + j];
+        v = pos ? pos[v] : v;
+      }
     }
     row[j] = v;
   }
@@ -1239,15 +1243,16 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // positions = the search grid's cell-sorted (Morton) order of THIS cloud when it is cached on the context
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
   int32_t* pos = nullptr;
+  const int32_t* npos = (order && ctx->npos_neigh == d_neigh && ctx->npos_k == K) ? ctx->seg_npos.as<int32_t>() : nullptr;
   (void)hipEventRecord(ctx->ev[8], st);
-  if (order) {
+  if (order && !npos) {
     pos = vmark;  // (free until the validation marks are cleared below)
     invert_order_kernel<<<nblk(n, 256), 256, 0, st>>>(order, n, pos);
   }
   if (KC == 16)
-    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, rec, prio);
+    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio);
   else
-    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, rec, prio);
+    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio);
   // static masks + reverse-list counts in one pass, offsets by a 64-bit exclusive scan over n + 1
   // entries (roff[n] = total), then the fill
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
                                                        double* __restrict__ normals,
                                                        int32_t* __restrict__ fb_list,
                                                        int32_t* __restrict__ fb_count, uint64_t cert_r2,
-                                                       unsigned long long* __restrict__ uncert)
+                                                       unsigned long long* __restrict__ uncert,
+                                                       int32_t* __restrict__ npos)
 {
   const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
   if (s >= g.n)
@@ -108,9 +109,15 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
                      (int)((uint32_t)(P.y - g.mn[1]) / (uint32_t)g.cell),
                      (int)((uint32_t)(P.z - g.mn[2]) / (uint32_t)g.cell)};
   uint64_t best[KC];
+  // cell-sorted POSITION of every kept candidate, carried through the insertion network as a payload:
+  // the region grower addresses points by position (bs_grow_spec.hip) and would otherwise have to look
+  // every neighbour up by its index -- one random HBM access per edge
+  int bpos[KC];
 #pragma unroll
-  for (int j = 0; j < KC; j++)
+  for (int j = 0; j < KC; j++) {
     best[j] = ~0ull;
+    bpos[j] = 0;
+  }
   Moments m = {};
   bool done = false;
   for (int rho = 0; rho <= BS_FAST_RINGS && !done; rho++) {
@@ -137,12 +144,16 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
             const uint32_t d2 = (uint32_t)(ex * ex) + (uint32_t)(ey * ey) + (uint32_t)(ez * ez);
             uint64_t key = ((uint64_t)d2 << 32) | (uint32_t)c.w;
             if (key < best[KC - 1]) {
+              int pay = t;
 #pragma unroll
               for (int j = 0; j < KC; j++) {
                 const bool lt = key < best[j];
                 const uint64_t hi = lt ? best[j] : key;
+                const int ph = lt ? bpos[j] : pay;
                 best[j] = lt ? key : best[j];
+                bpos[j] = lt ? pay : bpos[j];
                 key = hi;
+                pay = ph;
               }
             }
             if ((double)d2 < r2)
@@ -179,6 +190,13 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
   for (int j = 0; j < KC; j++)
     if (j < K)
       row[j] = (int32_t)(uint32_t)best[j];
+  if (npos) {  // rows in POSITION order: coalesced
+    int32_t* prow = npos + s * K;
+#pragma unroll
+    for (int j = 0; j < KC; j++)
+      if (j < K)
+        prow[j] = bpos[j];
+  }
   if (normals) {
     const V3 nv = normal_from_moments(m);
     double* o = normals + 3 * (int64_t)(loc - q_begin);
@@ -416,7 +434,8 @@ __device__ inline bool cand_less(uint64_t d2a, int32_t ia, uint64_t d2b, int32_t
   return d2a < d2b || (d2a == d2b && ia < ib);
 }
 
-__device__ inline void list_insert(uint64_t* d2s, int32_t* idxs, int& cnt, int cap, uint64_t d2, int32_t idx)
+__device__ inline void list_insert(uint64_t* d2s, int32_t* idxs, int32_t* poss, int& cnt, int cap, uint64_t d2, int32_t idx,
+                                   int32_t pos)
 {
   int c = cnt;
   if (c == cap) {
@@ -428,10 +447,12 @@ __device__ inline void list_insert(uint64_t* d2s, int32_t* idxs, int& cnt, int c
   while (j > 0 && cand_less(d2, idx, d2s[j - 1], idxs[j - 1])) {
     d2s[j] = d2s[j - 1];
     idxs[j] = idxs[j - 1];
+    poss[j] = poss[j - 1];
     j--;
   }
   d2s[j] = d2;
   idxs[j] = idx;
+  poss[j] = pos;
   cnt = c + 1;
 }
 
@@ -464,7 +485,8 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
                                                          const int32_t* __restrict__ fb_list,
                                                          const int32_t* __restrict__ fb_count,
                                                          uint64_t cert_r2,
-                                                         unsigned long long* __restrict__ uncert)
+                                                         unsigned long long* __restrict__ uncert,
+                                                         int32_t* __restrict__ npos)
 {
   const int total = *fb_count;
   for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += gridDim.x * blockDim.x) {
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
                        (int)((uint32_t)(P.y - g.mn[1]) / (uint32_t)g.cell),
                        (int)((uint32_t)(P.z - g.mn[2]) / (uint32_t)g.cell)};
     uint64_t kd2[32], md2[64];
-    int32_t kidx[32], mgid[64], mpos[64];
+    int32_t kidx[32], kpos[32], mgid[64], mpos[64];
     int kc = 0, mc = 0;
     bool done = false;
     for (int rho = 0; rho <= BS_GENERAL_RINGS && !done; rho++) {
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
               const int4 c = g.spts[t];
               const int64_t ex = (int64_t)c.x - q[0], ey = (int64_t)c.y - q[1], ez = (int64_t)c.z - q[2];
               const uint64_t d2 = (uint64_t)(ex * ex) + (uint64_t)(ey * ey) + (uint64_t)(ez * ez);
-              list_insert(kd2, kidx, kc, K, d2, c.w);
+              list_insert(kd2, kidx, kpos, kc, K, d2, c.w, t);
               if ((double)d2 < r2)
                 hybrid_insert(md2, mgid, mpos, mc, max_nn, d2, c.w, t);
             }
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
         const int4 c = g.spts[t];
         const int64_t ex = (int64_t)c.x - q[0], ey = (int64_t)c.y - q[1], ez = (int64_t)c.z - q[2];
         const uint64_t d2 = (uint64_t)(ex * ex) + (uint64_t)(ey * ey) + (uint64_t)(ez * ez);
-        list_insert(kd2, kidx, kc, K, d2, c.w);
+        list_insert(kd2, kidx, kpos, kc, K, d2, c.w, (int32_t)t);
         if ((double)d2 < r2)
           hybrid_insert(md2, mgid, mpos, mc, max_nn, d2, c.w, (int32_t)t);
       }
@@ -531,6 +553,9 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
     int32_t* row = neigh + (int64_t)(loc - q_begin) * K;
     for (int j = 0; j < K; j++)
       row[j] = kidx[j];
+    if (npos)
+      for (int j = 0; j < K; j++)
+        npos[(int64_t)s * K + j] = kpos[j];
     if (normals) {
       Moments m = {};
       for (int j = 0; j < mc; j++) {
@@ -563,7 +588,7 @@ __global__ void mark_all_kernel(GridDev g, int64_t q_begin, int64_t q_end, int32
 }  // namespace
 
 int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q_end, const bs_params& p,
-                       int32_t* d_neigh, double* d_normals, double cert_radius, int64_t* n_uncertified)
+                       int32_t* d_neigh, double* d_normals, double cert_radius, int64_t* n_uncertified, int32_t* d_npos)
 {
   hipStream_t st = ctx->stream;
   const int64_t n = g.n;
@@ -587,18 +612,18 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
   if (fast_ok) {
     // measured on MI355X: the LDS-staged variant is slower than the cache-served one
     // (1 M: 1.00 vs 0.58 ms, 50 M: 51.7 vs 24.3 ms) -- opt-in only
-    const bool untiled = getenv("BS_KNN_TILED") == nullptr;
+    const bool untiled = getenv("BS_KNN_TILED") == nullptr || d_npos != nullptr;  // (the tiled variant emits no positions)
     if (p.k <= 16) {
       if (untiled)
         knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                    fb_list, fb_count, cert_r2, uncert);
+                                                    fb_list, fb_count, cert_r2, uncert, d_npos);
       else
         knn_tile_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
                                                     fb_list, fb_count, cert_r2, uncert);
     } else {
       if (untiled)
         knn_fast_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                    fb_list, fb_count, cert_r2, uncert);
+                                                    fb_list, fb_count, cert_r2, uncert, d_npos);
       else
         knn_tile_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
                                                     fb_list, fb_count, cert_r2, uncert);
@@ -607,7 +632,7 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
     mark_all_kernel<<<blocks, 256, 0, st>>>(g, q_begin, q_end, fb_list, fb_count);
   }
   knn_general_kernel<<<1024, 64, 0, st>>>(g, q_begin, p.k, p.max_nn, r2, d_neigh, d_normals, fb_list,
-                                          fb_count, cert_r2, uncert);
+                                          fb_count, cert_r2, uncert, d_npos);
   BS_HIP(ctx, hipGetLastError());
   // bookkeeping read-back (also the point where kernel faults surface)
   int32_t hb[4];
