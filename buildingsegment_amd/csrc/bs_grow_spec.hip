@@ -293,6 +293,110 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
     *any = 1;
 }
 
+// ---- the FIRST fixed point (no plane yet) by decided states ------------------------------
+// Before any plane exists, "maker i occurs" only depends on the makers in R(i) with a LOWER
+// original index: i occurs iff none of them occurs.  Instead of starting optimistically and
+// undoing (the dirty-flag iteration above needed 4 evaluations and 1.6 flips per point on the
+// 50 M cloud, every flip marking ~14 neighbours), each point is decided ONCE, as soon as its
+// lower in-neighbours are: st = 0 undecided, 1 occurs, 2 does not.  A decision only reads
+// decided states, so it is final whatever the timing; states written during a pass may be picked
+// up in the same pass.  Afterwards one pass derives every owner from the occurring makers.
+__global__ void decide_init_kernel(const uint32_t* __restrict__ hmask, int64_t n, uint8_t* __restrict__ st,
+                                   uint8_t* __restrict__ bund)
+{
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const bool maker = c < n && hmask[c] != 0;
+  if (c < n)
+    st[c] = maker ? 0 : 2;
+  const int anym = __syncthreads_or(maker);
+  if (threadIdx.x == 0)
+    bund[blockIdx.x] = anym ? 1 : 0;
+}
+
+__global__ void decide_pass_kernel(int64_t n, int sub, const int32_t* __restrict__ prio,
+                                   const int64_t* __restrict__ roff, const int32_t* __restrict__ radj, uint8_t* st,
+                                   uint8_t* bund, int* any)
+{
+  __shared__ unsigned long long sub_mask;
+  __shared__ int left[64];
+  const int64_t nb256 = (n + 255) >> 8;
+  const int64_t g0 = (int64_t)blockIdx.x * sub;
+  if (threadIdx.x < 64) {
+    const int64_t gidx = g0 + threadIdx.x;
+    const bool d = (int)threadIdx.x < sub && gidx < nb256 && bund[gidx] != 0;
+    left[threadIdx.x] = 0;
+    const unsigned long long m = ballot64(d);
+    if (threadIdx.x == 0)
+      sub_mask = m;
+  }
+  __syncthreads();
+  unsigned long long gm = sub_mask;
+  bool undecided_left = false;
+  while (gm) {
+    const int t = __ffsll(gm) - 1;
+    gm &= gm - 1;
+    const int64_t c = ((g0 + t) << 8) + threadIdx.x;
+    bool mine_left = false;
+    if (c < n && __hip_atomic_load(st + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      const int32_t pc = prio[c];
+      bool lower_occ = false, lower_und = false;
+      const int64_t e1 = roff[c + 1];
+      for (int64_t e = roff[c]; e < e1; e++) {
+        const int32_t j = radj[e];
+        if (prio[j] < pc) {
+          const uint8_t sj = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          lower_occ = lower_occ || sj == 1;
+          lower_und = lower_und || sj == 0;
+        }
+      }
+      if (lower_occ)
+        __hip_atomic_store(st + c, (uint8_t)2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (!lower_und)
+        __hip_atomic_store(st + c, (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        mine_left = true;
+    }
+    if (mine_left)
+      left[t] = 1;  // benign race: everybody writes 1
+    undecided_left = undecided_left || mine_left;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && (int)threadIdx.x < sub && g0 + threadIdx.x < nb256)
+    bund[g0 + threadIdx.x] = left[threadIdx.x] ? 1 : 0;
+  if (undecided_left)
+    *any = 1;
+}
+
+// owners and occupancy bits from the decided states (one thread per position, 64 positions per wave)
+__global__ void decide_finish_kernel(int64_t n, const int32_t* __restrict__ prio, const int64_t* __restrict__ roff,
+                                     const int32_t* __restrict__ radj, const uint8_t* __restrict__ st,
+                                     int32_t* __restrict__ omega, uint32_t* __restrict__ occ, int4* rec, int quads)
+{
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool oc = false;
+  if (c < n) {
+    int32_t v = INF;
+    const int64_t e1 = roff[c + 1];
+    for (int64_t e = roff[c]; e < e1; e++) {
+      const int32_t j = radj[e];
+      if (st[j] == 1) {
+        const int32_t pj = prio[j];
+        v = pj < v ? pj : v;
+      }
+    }
+    omega[c] = v;
+    reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;
+    oc = st[c] == 1;
+  }
+  const unsigned long long m = ballot64(oc);
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (c - lane) >> 5;  // blockDim is a multiple of 64: the wave covers 64 aligned positions
+  if (lane == 0 && (c - lane) < n)
+    occ[w0] = (uint32_t)m;
+  if (lane == 32 && (c - lane + 32) < n)
+    occ[w0 + 1] = (uint32_t)(m >> 32);
+}
+
 // BS_VERIFY=1: is (omega, occ) a fixed point of the owner equations?
 __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ hmask, const int32_t* __restrict__ prio,
                                        const uint8_t* __restrict__ ps,
@@ -1267,24 +1371,43 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   unsigned long long* rcur = cand_raw;
   BS_HIP(ctx, hipMemcpyAsync(rcur, roff, sizeof(int64_t) * n, hipMemcpyDeviceToDevice, st));
   rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rec, quads, n, rcur, radj);
-  // initial state: no plane, every point dirty, nobody occurs yet (the first pass sets occ)
+  // initial state: no plane; the first owner fixed point is computed by decided states (see
+  // decide_pass_kernel), after which nothing is dirty
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
-  fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(omega, n, INF);
   BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(vmark, 0, sizeof(int32_t) * n, st));
-  BS_HIP(ctx, hipMemsetAsync(occ, 0, sizeof(uint32_t) * (size_t)((n + 31) / 32), st));
-  BS_HIP(ctx, hipMemsetAsync(dirty0, 1, n, st));
+  BS_HIP(ctx, hipMemsetAsync(occ, 0, sizeof(uint32_t) * (size_t)((n + 31) / 32 + 2), st));
+  int64_t passes = 0;
+  // 256-point groups per workgroup of a pass: enough workgroups to fill the chip in the heavy first
+  // passes, few enough that an (almost) idle pass costs microseconds
+  const int pull_sub = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)nb256 / 4096));
+  {
+    uint8_t* state = dirty1;   // scratch until the dirty flags are cleared below
+    uint8_t* bund = bdirty1;
+    decide_init_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, n, state, bund);
+    for (int it = 0;; it++) {
+      BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
+      decide_pass_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(n, pull_sub, prio, roff, radj, state, bund,
+                                                                                  d_misc);
+      int any = 0;
+      BS_HIP(ctx, hipMemcpyAsync(&any, d_misc, sizeof any, hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipStreamSynchronize(st));
+      passes++;
+      if (!any)
+        break;
+      if (it > 4 * 1000 * 1000)
+        return fail(ctx, BS_ERR_INTERNAL, "orphan fixed point (decided states) did not converge");
+    }
+    decide_finish_kernel<<<nblk(n, 256), 256, 0, st>>>(n, prio, roff, radj, state, omega, occ, rec, quads);
+  }
+  BS_HIP(ctx, hipMemsetAsync(dirty0, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(dirty1, 0, n, st));
-  BS_HIP(ctx, hipMemsetAsync(bdirty0, 1, nb256, st));
+  BS_HIP(ctx, hipMemsetAsync(bdirty0, 0, nb256, st));
   BS_HIP(ctx, hipMemsetAsync(bdirty1, 0, nb256, st));
   uint8_t* dcur = dirty0;
   uint8_t* dnext = dirty1;
   uint8_t* bcur = bdirty0;
   uint8_t* bnext = bdirty1;
-  int64_t passes = 0;
-  // 256-point groups per workgroup of a pull pass: enough workgroups to fill the chip in the heavy first
-  // passes, few enough that an (almost) idle pass costs microseconds
-  const int pull_sub = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)nb256 / 4096));
   auto propagate = [&]() -> int {
     for (int it = 0; it < 1000000; it++) {
       BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
