@@ -167,35 +167,61 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
 // order (nullable): a spatially coherent permutation (the grid's cell-sorted
 // order), so that the neighbour gathers of adjacent threads share cache lines.
 // Neighbour geometry comes from the one-line-per-point records.
-__global__ void static_mask_kernel(SpecArgs a, const int4* __restrict__ rec, int quads,
-                                   uint32_t* __restrict__ hmask, int32_t* __restrict__ rcnt)
+// Reverse-list counting / filling without one global atomic per edge.  Integer atomics are executed at
+// the memory side (64 uncached bytes each, whatever the locality): the 750 M edges of the 50 M cloud were
+// 48 GB of atomic traffic per pass.  In position space a point's neighbours sit within a few hundred
+// positions, so every workgroup (256 consecutive positions) counts the edges into its WINDOW of
+// RW_WIN positions in LDS and touches global memory once per distinct target; only the rare edge that
+// leaves the window takes the global atomic.
+constexpr int RW_PAD = 896;
+constexpr int RW_WIN = 256 + 2 * RW_PAD;  // 2048 positions
+
+__global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4* __restrict__ rec, int quads,
+                                                          uint32_t* __restrict__ hmask, int32_t* __restrict__ rcnt)
 {
-  const int64_t i = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;  // position: spatial neighbours are adjacent threads
-  if (i >= a.n)
-    return;
-  const int4* ri = rec + i * quads;
-  const int4 s0 = ri[0], s1 = ri[1], s2 = ri[2];
-  const double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z),
-               cnz = __hiloint2double(s2.y, s2.x);
-  const int ccx = s0.x, ccy = s0.y, ccz = s0.z;
-  const int32_t* row = reinterpret_cast<const int32_t*>(ri + 4);
-  uint32_t m = 0;
-  for (int t = 1; t < a.K; t++) {
-    const int4* rc = rec + (int64_t)row[t] * quads;
-    const int4 q0 = rc[0], q1 = rc[1];
-    const int2 q2 = *reinterpret_cast<const int2*>(rc + 2);
-    const int dx = (int)((uint32_t)q0.x - (uint32_t)ccx);
-    const int dy = (int)((uint32_t)q0.y - (uint32_t)ccy);
-    const int dz = (int)((uint32_t)q0.z - (uint32_t)ccz);
-    const double dist = __builtin_fabs((double)dx * cnx + (double)dy * cny + (double)dz * cnz);
-    const double dt = cnx * __hiloint2double(q1.y, q1.x) + cny * __hiloint2double(q1.w, q1.z) +
-                      cnz * __hiloint2double(q2.y, q2.x);
-    if (dist <= a.th && dt >= a.cos_th) {
-      m |= 1u << (t - 1);
-      atomicAdd(&rcnt[row[t]], 1);  // |R(c)|: the reverse lists are counted in the same pass
+  __shared__ int lcnt[RW_WIN];
+  const int64_t b0 = xcd_logical_block() * (int64_t)blockDim.x;
+  const int64_t i = b0 + threadIdx.x;  // position: spatial neighbours are adjacent threads
+  const int64_t w0 = b0 > RW_PAD ? b0 - RW_PAD : 0;
+  for (int d = threadIdx.x; d < RW_WIN; d += 256)
+    lcnt[d] = 0;
+  __syncthreads();
+  if (i < a.n) {
+    const int4* ri = rec + i * quads;
+    const int4 s0 = ri[0], s1 = ri[1], s2 = ri[2];
+    const double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z),
+                 cnz = __hiloint2double(s2.y, s2.x);
+    const int ccx = s0.x, ccy = s0.y, ccz = s0.z;
+    const int32_t* row = reinterpret_cast<const int32_t*>(ri + 4);
+    uint32_t m = 0;
+    for (int t = 1; t < a.K; t++) {
+      const int32_t c = row[t];
+      const int4* rc = rec + (int64_t)c * quads;
+      const int4 q0 = rc[0], q1 = rc[1];
+      const int2 q2 = *reinterpret_cast<const int2*>(rc + 2);
+      const int dx = (int)((uint32_t)q0.x - (uint32_t)ccx);
+      const int dy = (int)((uint32_t)q0.y - (uint32_t)ccy);
+      const int dz = (int)((uint32_t)q0.z - (uint32_t)ccz);
+      const double dist = __builtin_fabs((double)dx * cnx + (double)dy * cny + (double)dz * cnz);
+      const double dt = cnx * __hiloint2double(q1.y, q1.x) + cny * __hiloint2double(q1.w, q1.z) +
+                        cnz * __hiloint2double(q2.y, q2.x);
+      if (dist <= a.th && dt >= a.cos_th) {
+        m |= 1u << (t - 1);
+        const int64_t d = (int64_t)c - w0;  // |R(c)|: the reverse lists are counted in the same pass
+        if (d >= 0 && d < RW_WIN)
+          atomicAdd(&lcnt[d], 1);
+        else
+          atomicAdd(&rcnt[c], 1);
+      }
     }
+    hmask[i] = m;
   }
-  hmask[i] = m;
+  __syncthreads();
+  for (int d = threadIdx.x; d < RW_WIN; d += 256) {
+    const int v = lcnt[d];
+    if (v)
+      atomicAdd(&rcnt[w0 + d], v);
+  }
 }
 
 // ---- orphan-maker fixed point (dynamic, pull based) ----------------------------
@@ -206,19 +232,48 @@ __global__ void static_mask_kernel(SpecArgs a, const int4* __restrict__ rec, int
 // points until nothing flips.  Dependencies only run from lower to higher
 // indices, so the iteration settles bottom-up to the unique fixed point; work is
 // proportional to what actually changes, not to n.
-__global__ void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec, int quads, int64_t n,
-                                unsigned long long* __restrict__ rcur, int32_t* __restrict__ radj)
+__global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec,
+                                                       int quads, int64_t n, unsigned long long* __restrict__ rcur,
+                                                       int32_t* __restrict__ radj)
 {
-  const int64_t i = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n)
-    return;
-  uint32_t m = hmask[i];
-  const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
-  while (m) {
+  // same window as static_mask_kernel: count per target in LDS, reserve ONE range per (workgroup, target)
+  // with a global atomic on the target's fill cursor (rcur[c] starts at roff[c]), then hand out the slots
+  // of the range through LDS.  The order of a reverse list is irrelevant (only its minimum is ever taken).
+  __shared__ int lcnt[RW_WIN];
+  __shared__ unsigned long long lbase[RW_WIN];
+  const int64_t b0 = xcd_logical_block() * (int64_t)blockDim.x;
+  const int64_t i = b0 + threadIdx.x;
+  const int64_t w0 = b0 > RW_PAD ? b0 - RW_PAD : 0;
+  for (int d = threadIdx.x; d < RW_WIN; d += 256)
+    lcnt[d] = 0;
+  __syncthreads();
+  const uint32_t m0 = i < n ? hmask[i] : 0u;
+  const int32_t* row = reinterpret_cast<const int32_t*>(rec + (i < n ? i : 0) * quads + 4);
+  for (uint32_t m = m0; m;) {
+    const int t = __ffs(m) - 1;
+    m &= m - 1;
+    const int64_t d = (int64_t)row[t + 1] - w0;
+    if (d >= 0 && d < RW_WIN)
+      atomicAdd(&lcnt[d], 1);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < RW_WIN; d += 256) {
+    const int v = lcnt[d];
+    if (v) {
+      lbase[d] = atomicAdd(&rcur[w0 + d], (unsigned long long)v);
+      lcnt[d] = 0;
+    }
+  }
+  __syncthreads();
+  for (uint32_t m = m0; m;) {
     const int t = __ffs(m) - 1;
     m &= m - 1;
     const int32_t c = row[t + 1];
-    radj[atomicAdd(&rcur[c], 1ull)] = (int32_t)i;  // rcur[c] starts at roff[c]: ONE random access per edge
+    const int64_t d = (int64_t)c - w0;
+    if (d >= 0 && d < RW_WIN)
+      radj[lbase[d] + (unsigned)atomicAdd(&lcnt[d], 1)] = (int32_t)i;
+    else
+      radj[atomicAdd(&rcur[c], 1ull)] = (int32_t)i;
   }
 }
 
