@@ -21,11 +21,11 @@ SRC = os.path.join(ROOT, "buildingsegment_amd", "csrc", "bs_grow_spec.hip")
 
 PATCHES = [
     ('// wave-cooperative "realloc"',
-     '__device__ unsigned long long g_prof[16];\n#define PROBE(i) do { const long long _t = clock64(); pacc[i] += _t - tlast; '
+     '__device__ unsigned long long g_prof[32];\n#define PROBE(i) do { const long long _t = clock64(); pacc[i] += _t - tlast; '
      'tlast = _t; } while (0)\n\n// wave-cooperative "realloc"'),
     ('    auto step = [&](auto mode) -> int {\n      if (__builtin_expect(sp == 0, 0))\n        return 2;\n'
      '      if (__builtin_expect(++iters > iter_cap, 0)) {\n        status = ST_WATCHDOG;\n        return 2;\n      }\n',
-     '    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};\n    long long ncalls = 0, nexp = 0;\n    long long tlast = clock64();\n'
+     '    long long pacc[16] = {0};\n    long long ncalls = 0, nexp = 0;\n    long long tlast = clock64();\n'
      '    auto step = [&](auto mode) -> int {\n      if (__builtin_expect(sp == 0, 0))\n        return 2;\n'
      '      if (__builtin_expect(++iters > iter_cap, 0)) {\n        status = ST_WATCHDOG;\n        return 2;\n      }\n'
      '      ncalls++;\n      PROBE(7);\n'),
@@ -41,13 +41,21 @@ PATCHES = [
      '        lds_lo = sp - LDS_STACK;  // older entries were overwritten in LDS (still in HBM)\n      PROBE(6);\n      return 1;\n    };\n'),
     ('      while (step(std::integral_constant<int, 2>{}) != 2) {\n      }\n    }\n',
      '      while (step(std::integral_constant<int, 2>{}) != 2) {\n      }\n    }\n'
-     '    if (lane == 0 && ln > 20000) {\n      for (int i = 0; i < 8; i++)\n        atomicAdd(&g_prof[i], (unsigned long long)pacc[i]);\n'
+     '    if (lane == 0 && ln > 20000) {\n      for (int i = 0; i < 8; i++)\n        atomicAdd(&g_prof[i], (unsigned long long)pacc[i]);\n      for (int i = 8; i < 12; i++)\n        atomicAdd(&g_prof[12 + i], (unsigned long long)pacc[i]);\n'
      '      atomicAdd(&g_prof[8], (unsigned long long)ncalls);\n      atomicAdd(&g_prof[9], (unsigned long long)nexp);\n    }\n'),
+    ("      // settle last call's optimistic claims: the tag must carry my seed\n",
+     "      PROBE(8);\n      // settle last call's optimistic claims: the tag must carry my seed\n"),
+    ("      // side-effect free classification\n", "      PROBE(9);\n      // side-effect free classification\n"),
+    ("      // ---- walk the pending calls in order: consume empty ones, stop at the first that accepts ----\n",
+     "      PROBE(10);\n      // ---- walk the pending calls in order: consume empty ones, stop at the first that accepts ----\n"),
+    ("      const int rank = __popcll(am & ((1ull << lane) - 1ull));\n",
+     "      PROBE(11);\n      const int rank = __popcll(am & ((1ull << lane) - 1ull));\n"),
     ('    if (getenv("BS_DEBUG")) {\n      int cnt[6]',
-     '    if (getenv("BS_DEBUG")) {\n      unsigned long long hp[16];\n      hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp));\n'
+     '    if (getenv("BS_DEBUG")) {\n      unsigned long long hp[32];\n      hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp));\n'
      '      fprintf(stderr, "[prof] steps=%llu expansions=%llu | src+issue=%llu state=%llu wait=%llu geo+walk=%llu bookA=%llu listS=%llu '
      'push=%llu top=%llu (counter units per step, cumulative over rounds)\\n", hp[8], hp[9], hp[0] / (hp[8] + 1), hp[1] / (hp[8] + 1), '
      'hp[2] / (hp[8] + 1), hp[3] / (hp[8] + 1), hp[4] / (hp[8] + 1), hp[5] / (hp[8] + 1), hp[6] / (hp[8] + 1), hp[7] / (hp[8] + 1));\n'
+     '      fprintf(stderr, "[prof2] geo=%llu settle=%llu classify=%llu claims+walk=see geo+walk slabcheck=%llu (geo+walk above = claims and walk only; listS = after the slab check)\\n", hp[20] / (hp[8] + 1), hp[21] / (hp[8] + 1), hp[22] / (hp[8] + 1), hp[23] / (hp[8] + 1));\n'
      '      int cnt[6]'),
 ]
 
