@@ -106,3 +106,25 @@ def test_fullsize_digests_and_properties(gpu_ctx, workload):
     t0 = time.time()
     check_properties(xyz, k, neigh, normals, plane_idx, planes)
     print(f"[{workload}] properties {time.time() - t0:.1f}s", flush=True)
+
+
+def test_urban_200m_on_one_gpu_properties(gpu_ctx):
+    """BASELINE.json configs[4]'s data size -- the 200 M-point multi-building scene (synth.urban seed 5, k=16) --
+    through the whole path on ONE MI355X (it fits: ~90 GB of device buffers; n (k-1) = 3.0e9 reverse edges need
+    the 64-bit offsets).  The CPU oracle would need hours at this size, so there are no digests: the
+    size-independent properties are checked from the HIP outputs alone -- k-list order, unit normals, label
+    range, list membership / duplicates, and every plane's centre and normal recomputed from its returned
+    list (bit for bit).  Takes ~1 min of host time for the cloud."""
+    import bench
+    from buildingsegment_amd import api
+    t0 = time.time()
+    xyz, k = bench.make_cloud("urban_200m")
+    assert len(xyz) == 200_000_000 and k == 16
+    print(f"\n[urban_200m] cloud {time.time() - t0:.1f}s", flush=True)
+    t0 = time.time()
+    neigh, normals, plane_idx, planes = gpu_ctx.segment(xyz, api.default_params(k=k))
+    tm = gpu_ctx.timings()
+    print(f"[urban_200m] segment (host buffers) {time.time() - t0:.1f}s, device {tm['total_ms']:.0f} ms = "
+          f"{len(xyz) / tm['total_ms'] / 1e3:.0f} Mpoints/s, rounds {tm['rg_rounds']}, planes {len(planes)}", flush=True)
+    assert len(planes) > 5000 and int((plane_idx > 0).sum()) > 150_000_000
+    check_properties(xyz, k, neigh, normals, plane_idx, planes)
