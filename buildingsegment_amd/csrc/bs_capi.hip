@@ -189,6 +189,11 @@ void bs_destroy(bs_ctx* c)
   for (auto& e : c->ev)
     if (e)
       (void)hipEventDestroy(e);
+  for (auto& e : c->sev)
+    if (e)
+      (void)hipEventDestroy(e);
+  if (c->side)
+    (void)hipStreamDestroy(c->side);
   if (c->own_stream)
     (void)hipStreamDestroy(c->own_stream);
   delete c;

@@ -127,6 +127,8 @@ struct bs_ctx {
   int64_t rg_n = 0;
   bool rg_valid = false;
   int forge_mode = 0;  // bs_selftest_forge_next
+  hipStream_t side = nullptr;  // second stream of the grower (validate3 beside the owner passes)
+  hipEvent_t sev[2] = {nullptr, nullptr};
   // 2-D raster scratch (bs_raster.hip)
   bs::DevBuf rs_keys_in, rs_keys_out, rs_vals_in, rs_vals_out, rs_cnt, rs_img, rs_tmp;
   // cell-sorted order of the last grid build (vals_out): spatially coherent iteration for gathers

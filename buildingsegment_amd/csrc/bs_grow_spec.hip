@@ -96,6 +96,8 @@ struct PlaneOut {
   int32_t pad;         // host command for plane_apply_kernel
   int32_t thief;       // diagnostics: seed of the plane that took a point from this one (-1: none)
   int32_t seed_pos;    // position of the seed (seed itself is the ORIGINAL index: the priority)
+  int32_t v3ok;        // validate3 (runs beside the owner passes on a second stream): state reproducible from the list
+  int32_t pad4;
 };
 
 struct Pool {
@@ -1000,6 +1002,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
     const int dflag = ld_i32(dead + seed);
     o.thief = (dflag < 0 ? -dflag : dflag) - 1;
     o.seed_pos = seed_s;
+    o.v3ok = 1;
+    o.pad4 = 0;
     out[w] = o;
   }
 }
@@ -1144,8 +1148,7 @@ __global__ __launch_bounds__(V3T) void validate3_kernel(PlaneOut* out, int ncand
              ez == o.center[2];
     }
     if (!same) {
-      out[w].status = ST_STOLEN;  // never enters the structure; its seed is grown again next round
-      out[w].pad = 0;
+      out[w].v3ok = 0;  // the host treats the plane as inconsistent: dropped from the structure, grown again
       atomicAdd(rejects, 1);
       if (rejects[1] == o.seed + 1)
         rejects[2] = 1;
@@ -1562,6 +1565,12 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   };
   bool cand_listed = false;
   int32_t ncand_all = 0;
+  bool v3_pending = false;
+  if (!ctx->side) {
+    BS_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    BS_HIP(ctx, hipEventCreateWithFlags(&ctx->sev[0], hipEventDisableTiming));
+    BS_HIP(ctx, hipEventCreateWithFlags(&ctx->sev[1], hipEventDisableTiming));
+  }
   int32_t rejects_seen = 0;
   int refused_rounds = 0;
   int forge_mode = ctx->forge_mode;
@@ -1631,8 +1640,15 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       }
       validate1_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n, vmark,
                                              (int32_t)((rounds & 0x3fff) << 17), d_misc + 4);
-      if (do_validate3)
-        validate3_kernel<<<ncand, V3T, 0, st>>>(d_out, ncand, pool.base, rec, quads, d_misc + 4);
+      if (do_validate3) {
+        // beside the owner passes: it only reads the finished lists and the records' geometry, and is one
+        // wave of sequential f64 adds per plane -- the main stream's kernels are memory bound
+        BS_HIP(ctx, hipEventRecord(ctx->sev[0], st));
+        BS_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->sev[0], 0));
+        validate3_kernel<<<ncand, V3T, 0, ctx->side>>>(d_out, ncand, pool.base, rec, quads, d_misc + 4);
+        BS_HIP(ctx, hipEventRecord(ctx->sev[1], ctx->side));
+        v3_pending = true;
+      }
       reset_tags_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, K);
       // insert the finished planes and let the owners settle
       plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur, omega, occ, rec, quads);
@@ -1653,6 +1669,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, hipMemcpyAsync(&next_ncand_all, d_misc + 1, sizeof next_ncand_all, hipMemcpyDeviceToHost, st));
     int32_t rejects_now = 0;
     BS_HIP(ctx, hipMemcpyAsync(&rejects_now, d_misc + 4, sizeof rejects_now, hipMemcpyDeviceToHost, st));
+    if (v3_pending) {
+      BS_HIP(ctx, hipStreamWaitEvent(st, ctx->sev[1], 0));
+      v3_pending = false;
+    }
     if (ncand)
       BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
     h_pend.resize(npend);
@@ -1675,7 +1695,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
                 (long)rounds, w, o.seed, o.status, o.consistent, (long)o.list_n, (long)o.steps, (long)o.log_n, o.thief);
       if (o.status == ST_WATCHDOG)
         return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): watchdog");
-      if (o.status == ST_DONE && !o.consistent)
+      if (o.status == ST_DONE && (!o.consistent || !o.v3ok))
         first_bad = std::min(first_bad, o.seed);
       if (w == 0 && o.status == ST_NOMEM)
         nomem_lowest = true;
@@ -1733,7 +1753,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         o.pad = 0;  // command for plane_apply_kernel: 2 = drop
         if (o.status != ST_DONE)
           continue;  // never entered the structure
-        if (!o.consistent) {
+        if (!o.consistent || !o.v3ok) {
           o.pad = 2;
           dropped++;
           continue;  // re-enters as a candidate (or orphan maker) next round
