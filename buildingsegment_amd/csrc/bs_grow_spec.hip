@@ -480,20 +480,30 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
 __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec, int quads, int K,
                                  int64_t n, int32_t F, const int32_t* __restrict__ prio, const uint8_t* __restrict__ ps,
                                  const int32_t* __restrict__ omega, int32_t* min_idx,
-                                 unsigned long long* __restrict__ cand_out, int32_t* cand_count)
+                                 unsigned long long* __restrict__ cand_out, int32_t* cand_count, uint8_t* __restrict__ bcand)
 {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n)
+  // A 256-position group whose points can never seed again -- incomplete static masks, points
+  // owned by a FINAL attempt (owner < F; F only grows) -- is skipped for the rest of the call: in the late
+  // rounds of a large cloud almost every group is, and the scan costs microseconds instead of a pass over n.
+  if (!bcand[blockIdx.x])
     return;
-  bool c = false;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool c = false, alive = false;
   const uint32_t full = (K - 1 >= 32) ? 0xffffffffu : ((1u << (K - 1)) - 1u);
-  const int32_t pi = prio[i];
-  if (pi >= F && !ps[i] && hmask[i] == full && omega[i] >= pi) {
-    c = true;
-    const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
-    for (int t = 1; t < K; t++)
-      c = c && omega[row[t]] >= pi;
+  const int32_t pi = i < n ? prio[i] : 0;
+  if (i < n && hmask[i] == full) {
+    const int32_t oi = omega[i];
+    alive = !(oi < F);  // (a pending plane's seed counts as alive: the plane can still be dropped)
+    if (pi >= F && oi >= pi && !ps[i]) {
+      c = true;
+      const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
+      for (int t = 1; t < K; t++)
+        c = c && omega[row[t]] >= pi;
+    }
   }
+  const int any_alive = __syncthreads_or(alive);
+  if (threadIdx.x == 0 && !any_alive)
+    bcand[blockIdx.x] = 0;
   if (c && min_idx)
     atomicMin(min_idx, pi);
   if (c && cand_out)  // sparse: appended unordered as (original index << 32 | position), sorted afterwards
@@ -1319,6 +1329,13 @@ __global__ void label_kernel(const int32_t* __restrict__ owner, int64_t n, const
   plane_idx[dst] = 1 + lo;
 }
 
+__global__ void reset_dead_kernel(const unsigned long long* __restrict__ cand, int ncand, int32_t* __restrict__ dead)
+{
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < ncand)
+    dead[(int32_t)(cand[w] >> 32)] = 0;
+}
+
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
 {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1362,7 +1379,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   //                            (u8) flags | ps | occ | dirty0 | dirty1 | PlaneOut[MAX_WAVES + MAX_PENDING] | CopyDesc[]
   const size_t n_i32 = (size_t)(7 * n + planes_cap + 1024 + 128);
   const size_t nb256 = (size_t)((n + 255) / 256);
-  const size_t aux_bytes = sizeof(int32_t) * n_i32 + (size_t)5 * n + 2 * nb256 + 8192 +
+  const size_t aux_bytes = sizeof(int32_t) * n_i32 + (size_t)5 * n + 3 * nb256 + 8192 +
                            sizeof(PlaneOut) * (MAX_WAVES + MAX_PENDING) + sizeof(CopyDesc) * (MAX_WAVES + MAX_PENDING);
   BS_HIP(ctx, ctx->rg_aux.reserve(aux_bytes));
   BS_HIP(ctx, ctx->rg_stack.reserve(sizeof(int32_t) * pool_cap));
@@ -1387,7 +1404,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   uint8_t* dirty1 = dirty0 + n;
   uint8_t* bdirty0 = dirty1 + n;  // one flag per 256 points
   uint8_t* bdirty1 = bdirty0 + nb256;
-  PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(bdirty1 + nb256) + 255) & ~(uintptr_t)255);
+  uint8_t* bcand = bdirty1 + nb256;  // one flag per 256 positions: can the group still hold a plane seed?
+  PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(bcand + nb256) + 255) & ~(uintptr_t)255);
   PlaneOut* d_pend = d_out + MAX_WAVES;
   CopyDesc* d_copy = (CopyDesc*)(d_pend + MAX_PENDING);
   int32_t* radj = ctx->rg_radj.as<int32_t>();
@@ -1475,6 +1493,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   BS_HIP(ctx, hipMemsetAsync(dirty1, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(bdirty0, 0, nb256, st));
   BS_HIP(ctx, hipMemsetAsync(bdirty1, 0, nb256, st));
+  BS_HIP(ctx, hipMemsetAsync(bcand, 1, nb256, st));
+  BS_HIP(ctx, hipMemsetAsync(dead, 0, sizeof(int32_t) * n, st));
   uint8_t* dcur = dirty0;
   uint8_t* dnext = dirty1;
   uint8_t* bcur = bdirty0;
@@ -1566,6 +1586,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   bool cand_listed = false;
   int32_t ncand_all = 0;
   bool v3_pending = false;
+  bool dead_dirty = false;
   if (!ctx->side) {
     BS_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     BS_HIP(ctx, hipEventCreateWithFlags(&ctx->sev[0], hipEventDisableTiming));
@@ -1590,7 +1611,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // lowest NEW candidate sees exactly the owners this round starts from unless planes were dropped)
     if (!cand_listed) {
       BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
-      cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, nullptr, cand_raw, d_misc + 1);
+      cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, nullptr, cand_raw, d_misc + 1, bcand);
       BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
     }
@@ -1624,7 +1645,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         if (nb)
           fprintf(stderr, "[bs] VERIFY: %d records differ from a full refresh (round %ld)\n", nb, (long)rounds);
       }
-      BS_HIP(ctx, hipMemsetAsync(dead, 0, sizeof(int32_t) * n, st));
+      if (dead_dirty) {  // after a pool exhaustion stale tags can point at seeds outside the round's candidate list
+        BS_HIP(ctx, hipMemsetAsync(dead, 0, sizeof(int32_t) * n, st));
+        dead_dirty = false;
+      }
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
       (void)hipEventRecord(ctx->ev[6], st);
       if (KC == 16)
@@ -1650,6 +1674,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         v3_pending = true;
       }
       reset_tags_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, K);
+      // dead[] is only ever written for seeds of this round's attempts: clear exactly those (not 4 n bytes per round)
+      reset_dead_kernel<<<nblk(ncand, 256), 256, 0, st>>>(d_cand, ncand, dead);
       // insert the finished planes and let the owners settle
       plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur, omega, occ, rec, quads);
       rc = propagate();
@@ -1663,7 +1689,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // same pass, the candidate list of the next round
     const int32_t init2[2] = {0, INF};
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 1, init2, sizeof init2, hipMemcpyHostToDevice, st));
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, d_misc + 2, cand_raw, d_misc + 1);
+    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, d_misc + 2, cand_raw, d_misc + 1, bcand);
     int32_t new_min = INF, next_ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipMemcpyAsync(&next_ncand_all, d_misc + 1, sizeof next_ncand_all, hipMemcpyDeviceToHost, st));
@@ -1699,8 +1725,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         first_bad = std::min(first_bad, o.seed);
       if (w == 0 && o.status == ST_NOMEM)
         nomem_lowest = true;
-      if (o.status == ST_NOMEM)
+      if (o.status == ST_NOMEM) {
         full_refresh = true;  // its last claims may be neither listed nor reset
+        dead_dirty = true;
+      }
     }
     for (int w = 0; w < npend; w++)
       if (!h_pend[w].consistent)
