@@ -177,30 +177,55 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
 // leaves the window takes the global atomic.
 constexpr int RW_PAD = 896;
 constexpr int RW_WIN = 256 + 2 * RW_PAD;  // 2048 positions
+constexpr int GW_PAD = 384;               // geometry tile of static_mask_kernel: 1024 positions x 48 B = 48 KB of LDS (56 KB with the counters: static LDS stays below 64 KB)
+constexpr int GW_WIN = 256 + 2 * GW_PAD;
 
+// Static depth-0 masks.  One workgroup = 256 consecutive positions.  The geometry (position + normal, 48 B)
+// of the workgroup's WINDOW of positions is staged once into LDS with coalesced loads; a neighbour inside the
+// window (nearly all of them: neighbours in space are neighbours in Morton position) costs an LDS read, the
+// rare one outside a global gather.  Before, every one of the k-1 neighbour tests fetched three 16-byte pieces
+// of a 128-byte record through L2 -- 1.6 KB of fabric traffic per point.
 __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4* __restrict__ rec, int quads,
-                                                          uint32_t* __restrict__ hmask, int32_t* __restrict__ rcnt)
+                                                          const int4* __restrict__ geo, uint32_t* __restrict__ hmask,
+                                                          int32_t* __restrict__ rcnt)
 {
   __shared__ int lcnt[RW_WIN];
+  __shared__ int4 lgeo[GW_WIN * 3];
   const int64_t b0 = xcd_logical_block() * (int64_t)blockDim.x;
   const int64_t i = b0 + threadIdx.x;  // position: spatial neighbours are adjacent threads
   const int64_t w0 = b0 > RW_PAD ? b0 - RW_PAD : 0;
+  const int64_t g0 = b0 > GW_PAD ? b0 - GW_PAD : 0;
   for (int d = threadIdx.x; d < RW_WIN; d += 256)
     lcnt[d] = 0;
+  {
+    const int64_t gend = (g0 + GW_WIN < a.n ? g0 + GW_WIN : a.n) - g0;  // positions available in the tile
+    const int4* src = geo + 3 * g0;
+    for (int64_t t = threadIdx.x; t < 3 * gend; t += 256)
+      lgeo[t] = src[t];
+  }
   __syncthreads();
   if (i < a.n) {
-    const int4* ri = rec + i * quads;
-    const int4 s0 = ri[0], s1 = ri[1], s2 = ri[2];
+    const int4* own = lgeo + 3 * (i - g0);
+    const int4 s0 = own[0], s1 = own[1], s2 = own[2];
     const double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z),
                  cnz = __hiloint2double(s2.y, s2.x);
     const int ccx = s0.x, ccy = s0.y, ccz = s0.z;
-    const int32_t* row = reinterpret_cast<const int32_t*>(ri + 4);
+    const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
     uint32_t m = 0;
     for (int t = 1; t < a.K; t++) {
       const int32_t c = row[t];
-      const int4* rc = rec + (int64_t)c * quads;
-      const int4 q0 = rc[0], q1 = rc[1];
-      const int2 q2 = *reinterpret_cast<const int2*>(rc + 2);
+      const int64_t gd = (int64_t)c - g0;
+      int4 q0, q1, q2;
+      if (gd >= 0 && gd < GW_WIN) {
+        q0 = lgeo[3 * gd];
+        q1 = lgeo[3 * gd + 1];
+        q2 = lgeo[3 * gd + 2];
+      } else {
+        const int4* rc = geo + 3 * (int64_t)c;
+        q0 = rc[0];
+        q1 = rc[1];
+        q2 = rc[2];
+      }
       const int dx = (int)((uint32_t)q0.x - (uint32_t)ccx);
       const int dy = (int)((uint32_t)q0.y - (uint32_t)ccy);
       const int dz = (int)((uint32_t)q0.z - (uint32_t)ccz);
@@ -542,7 +567,8 @@ __global__ void invert_order_kernel(const int32_t* __restrict__ order, int64_t n
 // stage that has to look things up by original index.
 template <int KC>
 __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ order, const int32_t* __restrict__ pos,
-                                     const int32_t* __restrict__ npos, int4* __restrict__ rec, int32_t* __restrict__ prio)
+                                     const int32_t* __restrict__ npos, int4* __restrict__ rec, int32_t* __restrict__ prio,
+                                     int4* __restrict__ geo)
 {
   const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s >= a.n)
@@ -555,6 +581,9 @@ __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ ord
   r[1] = make_int4(__double2loint(nx), __double2hiint(nx), __double2loint(ny), __double2hiint(ny));
   r[2] = make_int4(__double2loint(nz), __double2hiint(nz), INF, 0);
   r[3] = make_int4(0, 0, 0, 0);
+  geo[3 * s] = r[0];  // compact geometry (48 B per position) for the LDS tiles of static_mask_kernel
+  geo[3 * s + 1] = r[1];
+  geo[3 * s + 2] = r[2];
   prio[s] = (int32_t)i;
   int row[KC];
 #pragma unroll
@@ -1432,6 +1461,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // (unsorted | sorted, one (original index << 32 | position) key each)
   BS_HIP(ctx, ctx->rg_geo.reserve(sizeof(unsigned long long) * 2 * (size_t)(n + 64)));
   unsigned long long* cand_raw = ctx->rg_geo.as<unsigned long long>();
+  BS_HIP(ctx, ctx->rg_gs.reserve(sizeof(int4) * 3 * (size_t)(n + 1)));  // compact geometry by position (setup only)
+  int4* gs = ctx->rg_gs.as<int4>();
   unsigned long long* d_cand = cand_raw + n + 64;
   // positions = the search grid's cell-sorted (Morton) order of THIS cloud when it is cached on the context
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
@@ -1443,13 +1474,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     invert_order_kernel<<<nblk(n, 256), 256, 0, st>>>(order, n, pos);
   }
   if (KC == 16)
-    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio);
+    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio, gs);
   else
-    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio);
+    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio, gs);
   // static masks + reverse-list counts in one pass, offsets by a 64-bit exclusive scan over n + 1
   // entries (roff[n] = total), then the fill
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));
-  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, rec, quads, hmask, rpos);
+  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, rec, quads, gs, hmask, rpos);
   {
     hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*> in(rpos, ToI64());
     size_t tb = 0;

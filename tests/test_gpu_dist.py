@@ -69,3 +69,25 @@ def test_two_process_sharded_run_on_one_gpu(oracle, tmp_path):
         assert g["nplanes"] == (len(pl["id"]) if r == 0 else -1)
         seen[g["idx"]] += 1
     assert (seen == 1).all()
+
+
+def test_bench_sharded_mode_end_to_end():
+    """`bench.py --gpus 2` (the driver's contract) sharding ONE cloud over two ranks: spawned by bench.py itself,
+    both ranks on this box's single GPU, collectives over gloo (host-staged inside dist._coll; with nccl the
+    same code hands device tensors to RCCL).  The JSON line must say what was measured."""
+    import json
+    import subprocess
+    env = dict(os.environ, BS_CLOUD_CACHE="")
+    env.pop("BS_CLOUD_CACHE")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload",
+                        "plane_cube_100k", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["points_total"] == 99946 and "replicas only" in d["config"]["parallelism"]
+    assert set(d["stages_ms"]) == {"partition_ms", "halo_ms", "knn_normals_ms", "gather_ms", "grow_ms"}
+    # a mislabelled run is refused: WORLD_SIZE (1 rank) != --gpus
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert q.returncode == 2 and "refusing" in q.stderr
