@@ -1724,12 +1724,12 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     int32_t new_min = INF, next_ncand_all = 0;
     BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipMemcpyAsync(&next_ncand_all, d_misc + 1, sizeof next_ncand_all, hipMemcpyDeviceToHost, st));
-    int32_t rejects_now = 0;
-    BS_HIP(ctx, hipMemcpyAsync(&rejects_now, d_misc + 4, sizeof rejects_now, hipMemcpyDeviceToHost, st));
-    if (v3_pending) {
+    if (v3_pending) {  // validate3's verdicts (PlaneOut.v3ok, the refusal counter) are read below
       BS_HIP(ctx, hipStreamWaitEvent(st, ctx->sev[1], 0));
       v3_pending = false;
     }
+    int32_t rejects_now = 0;
+    BS_HIP(ctx, hipMemcpyAsync(&rejects_now, d_misc + 4, sizeof rejects_now, hipMemcpyDeviceToHost, st));
     if (ncand)
       BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
     h_pend.resize(npend);
