@@ -309,7 +309,7 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
                                  const int32_t* __restrict__ base, const int64_t* __restrict__ roff,
                                  const int32_t* __restrict__ radj, int32_t* __restrict__ omega, uint32_t* occ,
                                  uint8_t* dirty_cur, uint8_t* dirty_next, uint8_t* bdirty_cur, uint8_t* bdirty_next,
-                                 int4* rec, int quads, int* any)
+                                 int4* rec, int quads, int* any, const int32_t* __restrict__ minr)
 {
   // Dirty flags on two levels: one per point and one per 256 points.  A workgroup owns `sub`
   // (<= 64) consecutive 256-point groups and visits only the dirty ones: late passes touch a few
@@ -338,14 +338,18 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
       continue;
     dirty_cur[c] = 0;
     int32_t v = base[c];
-    const int64_t e1 = roff[c + 1];
-    for (int64_t e = roff[c]; e < e1; e++) {
-      const int32_t j = radj[e];
-      // occ is a BITMAP (n / 8 bytes: 6 MB at 50 M points, resident in L2 / Infinity Cache), so the ~14
-      // random look-ups per re-evaluated point do not go to HBM
-      if ((__hip_atomic_load(occ + (j >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j & 31)) & 1u) {
-        const int32_t pj = prio[j];  // makers are compared by ORIGINAL index
-        v = pj < v ? pj : v;
+    // minr[c] = lowest original index in R(c): a base owner at or below it cannot be undercut by any maker,
+    // occurring or not -- the points of an inserted plane (base = its seed) skip the reverse list altogether
+    if (v > minr[c]) {
+      const int64_t e1 = roff[c + 1];
+      for (int64_t e = roff[c]; e < e1; e++) {
+        const int32_t j = radj[e];
+        // occ is a BITMAP (n / 8 bytes: 6 MB at 50 M points, resident in L2 / Infinity Cache), so the ~14
+        // random look-ups per re-evaluated point do not go to HBM
+        if ((__hip_atomic_load(occ + (j >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j & 31)) & 1u) {
+          const int32_t pj = prio[j];  // makers are compared by ORIGINAL index
+          v = pj < v ? pj : v;
+        }
       }
     }
     omega[c] = v;
@@ -452,20 +456,22 @@ __global__ void decide_pass_kernel(int64_t n, int sub, const int32_t* __restrict
 // owners and occupancy bits from the decided states (one thread per position, 64 positions per wave)
 __global__ void decide_finish_kernel(int64_t n, const int32_t* __restrict__ prio, const int64_t* __restrict__ roff,
                                      const int32_t* __restrict__ radj, const uint8_t* __restrict__ st,
-                                     int32_t* __restrict__ omega, uint32_t* __restrict__ occ, int4* rec, int quads)
+                                     int32_t* __restrict__ omega, uint32_t* __restrict__ occ, int4* rec, int quads,
+                                     int32_t* __restrict__ minr)
 {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool oc = false;
   if (c < n) {
-    int32_t v = INF;
+    int32_t v = INF, vall = INF;
     const int64_t e1 = roff[c + 1];
     for (int64_t e = roff[c]; e < e1; e++) {
       const int32_t j = radj[e];
-      if (st[j] == 1) {
-        const int32_t pj = prio[j];
+      const int32_t pj = prio[j];
+      vall = pj < vall ? pj : vall;
+      if (st[j] == 1)
         v = pj < v ? pj : v;
-      }
     }
+    minr[c] = vall;
     omega[c] = v;
     reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;
     oc = st[c] == 1;
@@ -1518,7 +1524,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       if (it > 4 * 1000 * 1000)
         return fail(ctx, BS_ERR_INTERNAL, "orphan fixed point (decided states) did not converge");
     }
-    decide_finish_kernel<<<nblk(n, 256), 256, 0, st>>>(n, prio, roff, radj, state, omega, occ, rec, quads);
+    decide_finish_kernel<<<nblk(n, 256), 256, 0, st>>>(n, prio, roff, radj, state, omega, occ, rec, quads, rpos);
   }
   BS_HIP(ctx, hipMemsetAsync(dirty0, 0, n, st));
   BS_HIP(ctx, hipMemsetAsync(dirty1, 0, n, st));
@@ -1535,7 +1541,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
       pull_pass_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(n, K, pull_sub, hmask, prio, ps, base, roff, radj,
                                                                                 omega, occ, dcur, dnext, bcur, bnext, rec, quads,
-                                                                                d_misc);
+                                                                                d_misc, rpos /* = minr after the setup */);
       int any = 0;
       BS_HIP(ctx, hipMemcpyAsync(&any, d_misc, sizeof any, hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
