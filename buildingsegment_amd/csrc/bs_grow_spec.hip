@@ -63,7 +63,7 @@ namespace bs {
 namespace {
 
 constexpr int32_t INF = 0x7fffffff;
-constexpr int MAX_WAVES = 65536;  // upper bound of plane attempts grown concurrently per round
+constexpr int MAX_WAVES = 1 << 20;  // upper bound of plane attempts grown per round
 constexpr int MAX_PENDING = 32768;  // finished planes waiting for earlier attempts
 
 enum : int32_t { ST_NONE = 0, ST_DONE = 1, ST_FAILED0 = 2, ST_NOMEM = 3, ST_WATCHDOG = 4, ST_STOLEN = 5 };
@@ -146,8 +146,8 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
   int64_t ncap = (int64_t)s.cap * 2;
   if (ncap < need)
     ncap = need;
-  if (ncap < 2048)
-    ncap = 2048;
+  if (ncap < 256)
+    ncap = 256;
   if (ncap > 0x7ffffff0ll)
     ncap = 0x7ffffff0ll;
   ncap = (ncap + 3) & ~(int64_t)3;  // keep slab offsets 16-byte aligned (int4 stack slots)
@@ -715,8 +715,9 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
     ccz = center_div((int32_t)Cz, cd);
     need_state = false;
   };
-  const bool have_mem = slab_ensure(pool, list, 0, 2048, lane) && slab_ensure(pool, stack, 0, 256 * (int64_t)KC, lane) &&
-                        slab_ensure(pool, log, 0, 2048, lane);
+  // first slabs are small: nine attempts in ten fail at depth 0 and never need more
+  const bool have_mem = slab_ensure(pool, list, 0, 256, lane) && slab_ensure(pool, stack, 0, 32 * (int64_t)KC, lane) &&
+                        slab_ensure(pool, log, 0, 256, lane);
   // A plane that loses a point to a sequentially earlier plane is invalid, but the
   // earlier plane's claims are visible: instead of waiting for the next round the
   // wave releases its claims and grows the plane again at once, now treating the
@@ -1399,14 +1400,19 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int retry_max_list = RETRY_MAX_LIST;
   if (const char* e = getenv("BS_RETRY_MAX_LIST"))
     retry_max_list = atoi(e);
-  // plane attempts per round: 50 M points, ~14 k candidates in the first rounds and 4 k+ consistent planes
-  // waiting behind them -- 8192 / 4096 (the first settings) cost 20 % there; 65536 is slower again
-  int max_waves = 32768;
+  // Plane attempts per round: ALL candidates.  A round is a barrier bounded by its longest plane, and the big
+  // planes of a large scene are independent of each other -- but their seeds are spread over the whole index
+  // range: with the lowest 32 768 candidates per round (round 1) the 50 M cloud grew its 136 k-, 131 k- and
+  // 122 k-entry planes one round AFTER the 80 k-entry one although nothing connected them (39 k + 68 k + 35 k
+  // sequential steps; a cap of 65 536 was worse still: 68 k + 66 k + 35 k).  The ~90 % of the attempts that fail
+  // at depth 0 cost one step and 1.5 KB of pool each.
+  int max_waves = MAX_WAVES;
   if (const char* e = getenv("BS_MAX_WAVES"))
     max_waves = atoi(e);
-  max_waves = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(max_waves, MAX_WAVES), n / 8 + 64));
+  const int wave_cap = (int)std::max<int64_t>(1, std::min<int64_t>(MAX_WAVES, n / 8 + 64));  // sizes the per-attempt arrays
+  max_waves = (int)std::max<int64_t>(1, std::min<int64_t>(max_waves, wave_cap));
   const unsigned long long pool_cap = (unsigned long long)std::max<int64_t>(
-      std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 2048 + 256 * 32) * 2 * max_waves);
+      std::min<int64_t>(64 * n, (int64_t)3 << 30), 8 * n + (int64_t)(2 * 256 + 32 * 32) * 2 * max_waves);
   BS_HIP(ctx, ctx->rg_list.reserve(sizeof(int32_t) * list_cap));
   BS_HIP(ctx, ctx->rg_planes.reserve(sizeof(PlaneRec) * planes_cap));
   BS_HIP(ctx, ctx->rg_stats.reserve(sizeof(GrowStats)));
@@ -1415,7 +1421,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const size_t n_i32 = (size_t)(7 * n + planes_cap + 1024 + 128);
   const size_t nb256 = (size_t)((n + 255) / 256);
   const size_t aux_bytes = sizeof(int32_t) * n_i32 + (size_t)5 * n + 3 * nb256 + 8192 +
-                           sizeof(PlaneOut) * (MAX_WAVES + MAX_PENDING) + sizeof(CopyDesc) * (MAX_WAVES + MAX_PENDING);
+                           sizeof(PlaneOut) * ((size_t)wave_cap + MAX_PENDING) +
+                           sizeof(CopyDesc) * ((size_t)wave_cap + MAX_PENDING);
   BS_HIP(ctx, ctx->rg_aux.reserve(aux_bytes));
   BS_HIP(ctx, ctx->rg_stack.reserve(sizeof(int32_t) * pool_cap));
   // reverse lists: <= n (k - 1) entries with 64-bit offsets (200 M points at k = 16 are 3.0e9 entries)
@@ -1441,7 +1448,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   uint8_t* bdirty1 = bdirty0 + nb256;
   uint8_t* bcand = bdirty1 + nb256;  // one flag per 256 positions: can the group still hold a plane seed?
   PlaneOut* d_out = (PlaneOut*)(((uintptr_t)(bcand + nb256) + 255) & ~(uintptr_t)255);
-  PlaneOut* d_pend = d_out + MAX_WAVES;
+  PlaneOut* d_pend = d_out + wave_cap;
   CopyDesc* d_copy = (CopyDesc*)(d_pend + MAX_PENDING);
   int32_t* radj = ctx->rg_radj.as<int32_t>();
   unsigned long long* d_pool_top = (unsigned long long*)(d_misc + 16);
@@ -1579,7 +1586,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
 
   std::vector<PlaneRec> recs;
   std::vector<int32_t> seeds;
-  std::vector<PlaneOut> h_out(MAX_WAVES), h_pend;
+  std::vector<PlaneOut> h_out, h_pend;
   std::vector<CopyDesc> copies;
   int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0, grow_launches = 0;
   double grow_ms = 0.0;
@@ -1611,8 +1618,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     return BS_OK;
   };
   auto flush_copies = [&]() -> int {
-    for (size_t off = 0; off < copies.size(); off += MAX_WAVES + MAX_PENDING) {
-      const int nd = (int)std::min<size_t>(copies.size() - off, MAX_WAVES + MAX_PENDING);
+    for (size_t off = 0; off < copies.size(); off += (size_t)wave_cap + MAX_PENDING) {
+      const int nd = (int)std::min<size_t>(copies.size() - off, (size_t)wave_cap + MAX_PENDING);
       BS_HIP(ctx, hipMemcpyAsync(d_copy, copies.data() + off, sizeof(CopyDesc) * nd, hipMemcpyHostToDevice, st));
       copy_lists_kernel<<<dim3(nd, 8), 256, 0, st>>>(d_copy, nd);
       BS_HIP(ctx, hipStreamSynchronize(st));  // descriptors are reused
@@ -1700,7 +1707,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         forge_mode = 0;
       }
       validate1_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, rec, quads, dead, n, vmark,
-                                             (int32_t)((rounds & 0x3fff) << 17), d_misc + 4);
+                                             (int32_t)((rounds & 0x3ff) << 20), d_misc + 4);
       if (do_validate3) {
         // beside the owner passes: it only reads the finished lists and the records' geometry, and is one
         // wave of sequential f64 adds per plane -- the main stream's kernels are memory bound
@@ -1736,6 +1743,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     }
     int32_t rejects_now = 0;
     BS_HIP(ctx, hipMemcpyAsync(&rejects_now, d_misc + 4, sizeof rejects_now, hipMemcpyDeviceToHost, st));
+    if ((int)h_out.size() < ncand)
+      h_out.resize(ncand);
     if (ncand)
       BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
     h_pend.resize(npend);
