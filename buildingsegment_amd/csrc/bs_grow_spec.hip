@@ -63,7 +63,7 @@ namespace bs {
 namespace {
 
 constexpr int32_t INF = 0x7fffffff;
-constexpr int MAX_WAVES = 1 << 20;  // upper bound of plane attempts grown per round
+constexpr int MAX_WAVES = 1 << 18;  // upper bound of plane attempts grown per round (the 50 M cloud has 158 k candidates in round 1)
 constexpr int MAX_PENDING = 32768;  // finished planes waiting for earlier attempts
 
 enum : int32_t { ST_NONE = 0, ST_DONE = 1, ST_FAILED0 = 2, ST_NOMEM = 3, ST_WATCHDOG = 4, ST_STOLEN = 5 };
@@ -1411,7 +1411,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // range: with the lowest 32 768 candidates per round (round 1) the 50 M cloud grew its 136 k-, 131 k- and
   // 122 k-entry planes one round AFTER the 80 k-entry one although nothing connected them (39 k + 68 k + 35 k
   // sequential steps; a cap of 65 536 was worse still: 68 k + 66 k + 35 k).  The ~90 % of the attempts that fail
-  // at depth 0 cost one step and 1.5 KB of pool each.
+  // at depth 0 cost one step and 1.5 KB of pool each.  (Bounded at 2^18: with 655 k attempts on the 200 M scene the
+  // round pool outgrew 16 GB and the FIRST call on a fresh context took 3 s longer; 2^18 keeps the pool at 12 GB.)
   int max_waves = MAX_WAVES;
   if (const char* e = getenv("BS_MAX_WAVES"))
     max_waves = atoi(e);
