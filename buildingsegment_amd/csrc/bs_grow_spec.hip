@@ -622,6 +622,7 @@ __global__ void refresh_records_kernel(const int32_t* __restrict__ omega, int4* 
 
 constexpr int LDS_STACK = 256;  // LIFO entries (with rows) kept in LDS
 constexpr int LDS_REFILL = 128;  // entries brought back from HBM when the pops reach below the window
+constexpr int MAX_RETRY_LONG = 3; // ... of which at most this many after a long list was thrown away
 constexpr int MAX_RETRY = 12;    // in-launch re-growths of a plane that lost a point ...
 constexpr int RETRY_MAX_LIST = 16384;  // ... as long as little work is thrown away (long planes wait for the next
                                       // round: their logged assumptions rarely survive their neighbours' insertion)
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
   const int32_t seed = (int32_t)(cand[w] >> 32);         // original index: what claims and owners are compared by
   const int32_t seed_s = (int32_t)(uint32_t)cand[w];     // position: where the seed's record lives
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
+  int long_tries = 0;
   // 32-bit bookkeeping (n < 2^31): 64-bit scalar arithmetic doubles the SALU work of every call
   int ln = 1, sp = 0, lds_lo = 0, logn = 0;
   uint32_t iters = 0;
@@ -1007,7 +1009,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
     if (ballot64(lost))
       status = ST_STOLEN;
   }
-  if (status != ST_STOLEN || attempt >= MAX_RETRY || ln > retry_max_list)
+  // (a LONG plane -- more than RETRY_MAX_LIST entries thrown away -- gets at most MAX_RETRY_LONG further tries)
+  if (status != ST_STOLEN || attempt >= MAX_RETRY || ln > retry_max_list || (ln > RETRY_MAX_LIST && ++long_tries > MAX_RETRY_LONG))
     break;
   // release this incarnation's claims (points taken over by others keep their new tag) ...
   for (int t = 1 + lane; t < ln; t += 64)
