@@ -79,7 +79,7 @@ def _worker(rank, world, port, halo, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo", [(2, 250.0), (2, 30.0), (3, 200.0)])
+@pytest.mark.parametrize("world,halo", [(2, 250.0), (2, 30.0), (3, 200.0), (5, 150.0)])
 def test_sharded_run_equals_single_process(oracle, tmp_path, world, halo):
     from buildingsegment_amd import synth
     out = str(tmp_path / "r%d.npz")
