@@ -43,6 +43,39 @@ struct DevBuf {
   }
 };
 
+// page-locked host staging (device-to-host results the host loop reads every round: a pageable
+// destination goes through the runtime's bounce buffer in chunks, with the GPU idle in between)
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes)
+  {
+    if (bytes <= cap)
+      return hipSuccess;
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess)
+      cap = want;
+    return e;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const
+  {
+    return (T*)p;
+  }
+};
+
 // ---- search grid (hashed uniform cells over the cell-sorted cloud) --------
 struct CellEntry {  // 16 B: one dwordx4 per probe
   uint64_t key;     // packed cell coords, ~0 = empty slot
@@ -124,6 +157,7 @@ struct bs_ctx {
   bs::DevBuf seg_neigh, seg_normals;
   // region-grow state
   bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec, rg_radj, rg_roff, rg_geo, rg_gs;
+  bs::HostBuf rg_hout;  // PlaneOut[wave_cap + MAX_PENDING] + a few scalars, page-locked
   int64_t rg_n = 0;
   bool rg_valid = false;
   int forge_mode = 0;  // bs_selftest_forge_next

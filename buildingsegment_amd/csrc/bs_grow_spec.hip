@@ -1553,19 +1553,32 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   uint8_t* dnext = dirty1;
   uint8_t* bcur = bdirty0;
   uint8_t* bnext = bdirty1;
+  // per-round results read by the host: page-locked (158 k attempts in the first round of the 50 M cloud are
+  // 18 MB each way)
+  BS_HIP(ctx, ctx->rg_hout.reserve(sizeof(PlaneOut) * ((size_t)wave_cap + MAX_PENDING) + 256));
+  PlaneOut* const h_out = ctx->rg_hout.as<PlaneOut>();
+  PlaneOut* const h_pend = h_out + wave_cap;
+  int32_t* const h_flags = reinterpret_cast<int32_t*>(h_pend + MAX_PENDING);  // small scalars copied back per pass / round
+  // The passes are launched in groups of PULL_GROUP with ONE host round trip per group: a pass that finds
+  // nothing dirty costs microseconds, a round trip ~50 us, and a plane insertion settles in 8-25 passes.
+  // Every pass reports its flips in its own word; the structure is a fixed point when the LAST pass of a
+  // group flipped nothing (the passes after the settling one find no dirty point and do nothing).
+  constexpr int PULL_GROUP = 4;
+  int32_t* const d_flip = d_misc + 24;
   auto propagate = [&]() -> int {
     for (int it = 0; it < 1000000; it++) {
-      BS_HIP(ctx, hipMemsetAsync(d_misc, 0, sizeof(int), st));
-      pull_pass_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(n, K, pull_sub, hmask, prio, ps, base, roff, radj,
-                                                                                omega, occ, dcur, dnext, bcur, bnext, rec, quads,
-                                                                                d_misc, rpos /* = minr after the setup */);
-      int any = 0;
-      BS_HIP(ctx, hipMemcpyAsync(&any, d_misc, sizeof any, hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipMemsetAsync(d_flip, 0, sizeof(int32_t) * PULL_GROUP, st));
+      for (int g = 0; g < PULL_GROUP; g++) {
+        pull_pass_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(n, K, pull_sub, hmask, prio, ps, base, roff, radj,
+                                                                                  omega, occ, dcur, dnext, bcur, bnext, rec, quads,
+                                                                                  d_flip + g, rpos /* = minr after the setup */);
+        passes++;
+        std::swap(dcur, dnext);  // dcur now holds the newly dirtied points (the old dcur was cleared by the pass)
+        std::swap(bcur, bnext);
+      }
+      BS_HIP(ctx, hipMemcpyAsync(h_flags, d_flip, sizeof(int32_t) * PULL_GROUP, hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
-      passes++;
-      std::swap(dcur, dnext);  // dcur now holds the newly dirtied points (the old dcur was cleared by the pass)
-      std::swap(bcur, bnext);
-      if (!any) {
+      if (!h_flags[PULL_GROUP - 1]) {
         if (getenv("BS_VERIFY")) {
           BS_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, sizeof(int), st));
           verify_fixpoint_kernel<<<nblk(n, 256), 256, 0, st>>>(n, hmask, prio, ps, base, roff, radj, omega, occ, d_misc + 3);
@@ -1596,7 +1609,6 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
 
   std::vector<PlaneRec> recs;
   std::vector<int32_t> seeds;
-  std::vector<PlaneOut> h_out, h_pend;
   std::vector<CopyDesc> copies;
   int64_t list_used = 0, largest = 0, attempts = 0, rounds = 0, grow_launches = 0;
   double grow_ms = 0.0;
@@ -1666,8 +1678,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     if (!cand_listed) {
       BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
       cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, nullptr, cand_raw, d_misc + 1, bcand);
-      BS_HIP(ctx, hipMemcpyAsync(&ncand_all, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipMemcpyAsync(h_flags + 11, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
+      ncand_all = h_flags[11];
     }
     cand_listed = false;
     if (ncand_all == 0 && npend == 0)
@@ -1749,23 +1762,19 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     const int32_t init2[2] = {0, INF};
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 1, init2, sizeof init2, hipMemcpyHostToDevice, st));
     cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, d_misc + 2, cand_raw, d_misc + 1, bcand);
-    int32_t new_min = INF, next_ncand_all = 0;
-    BS_HIP(ctx, hipMemcpyAsync(&new_min, d_misc + 2, sizeof new_min, hipMemcpyDeviceToHost, st));
-    BS_HIP(ctx, hipMemcpyAsync(&next_ncand_all, d_misc + 1, sizeof next_ncand_all, hipMemcpyDeviceToHost, st));
+    // (d_misc[1] = number of candidates listed, d_misc[2] = the lowest one: one copy into the page-locked flags)
+    BS_HIP(ctx, hipMemcpyAsync(h_flags + 8, d_misc + 1, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (v3_pending) {  // validate3's verdicts (PlaneOut.v3ok, the refusal counter) are read below
       BS_HIP(ctx, hipStreamWaitEvent(st, ctx->sev[1], 0));
       v3_pending = false;
     }
-    int32_t rejects_now = 0;
-    BS_HIP(ctx, hipMemcpyAsync(&rejects_now, d_misc + 4, sizeof rejects_now, hipMemcpyDeviceToHost, st));
-    if ((int)h_out.size() < ncand)
-      h_out.resize(ncand);
+    BS_HIP(ctx, hipMemcpyAsync(h_flags + 10, d_misc + 4, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (ncand)
-      BS_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
-    h_pend.resize(npend);
+      BS_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
     if (npend)
-      BS_HIP(ctx, hipMemcpyAsync(h_pend.data(), d_pend, sizeof(PlaneOut) * npend, hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipMemcpyAsync(h_pend, d_pend, sizeof(PlaneOut) * npend, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
+    const int32_t next_ncand_all = h_flags[8], new_min = h_flags[9], rejects_now = h_flags[10];
     if (timed_round) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess)
@@ -1879,11 +1888,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       return rc;
     if (dropped) {
       if (ncand) {
-        BS_HIP(ctx, hipMemcpyAsync(d_out, h_out.data(), sizeof(PlaneOut) * ncand, hipMemcpyHostToDevice, st));
+        BS_HIP(ctx, hipMemcpyAsync(d_out, h_out, sizeof(PlaneOut) * ncand, hipMemcpyHostToDevice, st));
         plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur, omega, occ, rec, quads);
       }
       if (npend) {
-        BS_HIP(ctx, hipMemcpyAsync(d_pend, h_pend.data(), sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
+        BS_HIP(ctx, hipMemcpyAsync(d_pend, h_pend, sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
         plane_apply_kernel<<<npend, VT, 0, st>>>(d_pend, npend, pstore, base, ps, dcur, bcur, omega, occ, rec, quads);
       }
       rc = propagate();
