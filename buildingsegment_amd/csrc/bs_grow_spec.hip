@@ -1109,23 +1109,100 @@ __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand,
 // LDS and one lane adds them in order (three independent chains); the other waves form the
 // order-independent integer sum.
 constexpr int V3T = 256;
+constexpr int V3C = 1024;  // list entries per staged chunk
 __global__ __launch_bounds__(V3T) void validate3_kernel(PlaneOut* out, int ncand, const int32_t* __restrict__ pool,
                                                         const int4* __restrict__ rec, int quads, int* rejects)
 {
-  __shared__ double sn[2][64][3];
+  __shared__ double sn[2][V3C][3];  // two staged chunks of normals (48 KB)
   __shared__ uint32_t sc[V3T / 64][3];
   const int w = blockIdx.x;
   if (w >= ncand || out[w].status != ST_DONE || out[w].pad != 1)  // pad == 1: passed validate1
     return;
   const PlaneOut o = out[w];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // integer sum (wraps mod 2^32): all threads
+  // The f64 sums must be taken in list order (one chain of dependent additions per coordinate): wave 0 walks
+  // them.  What bounds the kernel is feeding that chain: a list entry is two dependent gathers (position,
+  // then record) of ~1 us each, so the whole block stages V3C entries at a time into LDS, double-buffered --
+  // the gathers of chunk c + 1 are in flight while wave 0 adds chunk c.  (One wave staging 64 entries ahead
+  // spent 1.3 us per 64 entries waiting: 2.2 ms for the facade's 108 k-point plane; this form 0.5 ms.)
+  // The wrapping integer sums ride along on the same gathers.
   uint32_t cx = 0, cy = 0, cz = 0;
-  for (int64_t t = tid; t < o.list_n; t += V3T) {
-    const int4 q0 = rec[(int64_t)pool[o.list_off + t] * quads];
-    cx += (uint32_t)q0.x;
-    cy += (uint32_t)q0.y;
-    cz += (uint32_t)q0.z;
+  double rr[V3C / V3T][3];
+  auto fetch = [&](int64_t c) {
+#pragma unroll
+    for (int u = 0; u < V3C / V3T; u++) {
+      const int64_t t = c * V3C + u * V3T + tid;
+      if (t < o.list_n) {
+        const int4* r = rec + (int64_t)pool[o.list_off + t] * quads;
+        const int4 q0 = r[0], q1 = r[1], q2 = r[2];
+        cx += (uint32_t)q0.x;
+        cy += (uint32_t)q0.y;
+        cz += (uint32_t)q0.z;
+        rr[u][0] = __hiloint2double(q1.y, q1.x);
+        rr[u][1] = __hiloint2double(q1.w, q1.z);
+        rr[u][2] = __hiloint2double(q2.y, q2.x);
+      }
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < V3C / V3T; u++) {
+      sn[buf][u * V3T + tid][0] = rr[u][0];
+      sn[buf][u * V3T + tid][1] = rr[u][1];
+      sn[buf][u * V3T + tid][2] = rr[u][2];
+    }
+  };
+  const int64_t chunks = (o.list_n + V3C - 1) / V3C;
+  // lane c (0, 1, 2) of wave 0 carries coordinate c, so ONE LDS read + ONE v_add_f64 per list entry serve all
+  // three chains (every lane runs the same code on coordinate lane % 3: no divergence, the copies are ignored)
+  double acc = 0.0;
+  fetch(0);
+  put(0);
+  __syncthreads();
+  for (int64_t c = 0; c < chunks; c++) {
+    const int buf = (int)(c & 1);
+    if (c + 1 < chunks)
+      fetch(c + 1);
+    if (wv == 0) {
+      const int cnt = (int)((o.list_n - c * V3C < V3C) ? o.list_n - c * V3C : V3C);
+      const double* src = &sn[buf][0][lane % 3];
+      int e0 = 0;
+      if (cnt == V3C) {
+        // batches of 16 entries, the reads of the next batch issued BEFORE the additions of the current one
+        // (left to itself the compiler emits read - wait - two additions - read ...: one full LDS latency per
+        // two entries, 45 cycles per entry; this form is bound by the chain of additions)
+        double va[16], vb[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          va[i] = src[i * 3];
+        for (int b = 0; b < V3C / 16; b += 2) {
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            vb[i] = src[((b + 1) * 16 + i) * 3];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            acc += va[i];
+          __builtin_amdgcn_sched_barrier(0);
+          if (b + 2 < V3C / 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+              va[i] = src[((b + 2) * 16 + i) * 3];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            acc += vb[i];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        e0 = V3C;
+      }
+      for (; e0 < cnt; e0++)
+        acc += src[e0 * 3];
+    }
+    if (c + 1 < chunks)
+      put(buf ^ 1);
+    __syncthreads();  // chunk c + 1 is staged, chunk c's buffer is free again
   }
   for (int off = 32; off > 0; off >>= 1) {
     cx += (uint32_t)__shfl_xor((int)cx, off);
@@ -1137,44 +1214,7 @@ __global__ __launch_bounds__(V3T) void validate3_kernel(PlaneOut* out, int ncand
     sc[wv][1] = cy;
     sc[wv][2] = cz;
   }
-  // f64 sum in list order: wave 0, double-buffered staging
-  double Sx = 0.0, Sy = 0.0, Sz = 0.0;
-  if (wv == 0) {
-    const int64_t trips = (o.list_n + 63) / 64;
-    double rx = 0, ry = 0, rz = 0;
-    auto fetch = [&](int64_t trip) {  // the next 64 normals into registers (loads in flight during the adds)
-      const int64_t t = trip * 64 + lane;
-      if (t < o.list_n) {
-        const int4* r = rec + (int64_t)pool[o.list_off + t] * quads;
-        const int4 q1 = r[1], q2 = r[2];
-        rx = __hiloint2double(q1.y, q1.x);
-        ry = __hiloint2double(q1.w, q1.z);
-        rz = __hiloint2double(q2.y, q2.x);
-      }
-    };
-    auto put = [&](int buf) {
-      sn[buf][lane][0] = rx;
-      sn[buf][lane][1] = ry;
-      sn[buf][lane][2] = rz;
-    };
-    fetch(0);
-    put(0);
-    for (int64_t trip = 0; trip < trips; trip++) {
-      const int buf = (int)(trip & 1);
-      if (trip + 1 < trips)
-        fetch(trip + 1);
-      const int cnt = (int)((o.list_n - trip * 64 < 64) ? o.list_n - trip * 64 : 64);
-      if (lane == 0) {  // LDS operations of one wave complete in issue order: the values put() wrote are visible
-        for (int e = 0; e < cnt; e++) {
-          Sx += sn[buf][e][0];
-          Sy += sn[buf][e][1];
-          Sz += sn[buf][e][2];
-        }
-      }
-      if (trip + 1 < trips)
-        put(buf ^ 1);
-    }
-  }
+  const double Sx = __shfl(acc, 0), Sy = __shfl(acc, 1), Sz = __shfl(acc, 2);  // meaningful in wave 0 (tid 0 reads them)
   __syncthreads();
   if (tid == 0) {
     uint32_t Cx = 0, Cy = 0, Cz = 0;
