@@ -342,14 +342,27 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
     // occurring or not -- the points of an inserted plane (base = its seed) skip the reverse list altogether
     if (v > minr[c]) {
       const int64_t e1 = roff[c + 1];
-      for (int64_t e = roff[c]; e < e1; e++) {
-        const int32_t j = radj[e];
+      // four reverse edges at a time, each level of the dependent chain (edge -> occurrence bit -> original
+      // index) issued for all four before the first is waited for: a late pass re-evaluates a few hundred
+      // points and is bound by this chain's latency (~14 edges x 3 loads one after the other: 30 us per pass)
+      for (int64_t e = roff[c]; e < e1; e += 4) {
+        int32_t j[4];
+        uint32_t ow[4];
+        int32_t pj[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          j[i] = e + i < e1 ? radj[e + i] : -1;
         // occ is a BITMAP (n / 8 bytes: 6 MB at 50 M points, resident in L2 / Infinity Cache), so the ~14
         // random look-ups per re-evaluated point do not go to HBM
-        if ((__hip_atomic_load(occ + (j >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (j & 31)) & 1u) {
-          const int32_t pj = prio[j];  // makers are compared by ORIGINAL index
-          v = pj < v ? pj : v;
-        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          ow[i] = j[i] >= 0 ? __hip_atomic_load(occ + (j[i] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          pj[i] = ((ow[i] >> (j[i] & 31)) & 1u) ? prio[j[i]] : INF;  // makers are compared by ORIGINAL index
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          v = pj[i] < v ? pj[i] : v;
       }
     }
     omega[c] = v;
@@ -1354,18 +1367,21 @@ __global__ __launch_bounds__(VT) void validate2_kernel(PlaneOut* out, int ncand,
     return;
   const PlaneOut o = out[w];
   const int32_t s = o.seed;
-  bool bad = false;
+  bool bad1 = false, bad2 = false, bad3 = false;
   if (threadIdx.x == 0)
-    bad = omega[o.seed_pos] < s;  // (1) the seed is still free at its time ...
+    bad1 = omega[o.seed_pos] < s;  // (1) the seed is still free at its time ...
   if (threadIdx.x >= 1 && threadIdx.x < K)  // ... and so are its K-1 neighbours
-    bad = omega[reinterpret_cast<const int32_t*>(rec + (int64_t)o.seed_pos * quads + 4)[threadIdx.x]] < s;
+    bad1 = omega[reinterpret_cast<const int32_t*>(rec + (int64_t)o.seed_pos * quads + 4)[threadIdx.x]] < s;
   for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT)  // (2) accepted points were free
-    bad = bad || omega[pool[o.list_off + t]] < s;
+    bad2 = bad2 || omega[pool[o.list_off + t]] < s;
   for (int64_t t = threadIdx.x; t < o.log_n; t += VT)  // (3) assumed-taken points are taken
-    bad = bad || !(omega[pool[o.log_off + t]] < s);
-  const int b = __syncthreads_or(bad);
-  if (threadIdx.x == 0)
+    bad3 = bad3 || !(omega[pool[o.log_off + t]] < s);
+  const int b = __syncthreads_or((bad1 ? 1 : 0) | (bad2 ? 2 : 0) | (bad3 ? 4 : 0));
+  const int b2 = __syncthreads_or(bad2), b3 = __syncthreads_or(bad3);
+  if (threadIdx.x == 0) {
     out[w].consistent = b ? 0 : 1;
+    out[w].pad4 = (b && !b2 && !b3 ? 1 : 0) | (b2 ? 2 : 0) | (b3 ? 4 : 0);  // diagnostics (BS_DEBUG): which test failed
+  }
 }
 
 struct CopyDesc {
@@ -1702,6 +1718,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int refused_rounds = 0;
   int forge_mode = ctx->forge_mode;
   ctx->forge_mode = 0;
+  const bool dbg = getenv("BS_DEBUG") != nullptr;  // (not once per attempt: 158 k of them in a first round)
   const bool do_validate3 = getenv("BS_NO_VALIDATE3") == nullptr;  // developer A/B switch
   BS_HIP(ctx, hipMemsetAsync(d_misc + 4, 0, 3 * sizeof(int), st));  // [4] refused planes, [5] forged seed + 1, [6] forged one refused
   for (;;) {
@@ -1826,7 +1843,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     bool nomem_lowest = false;
     for (int w = 0; w < ncand; w++) {
       const PlaneOut& o = h_out[w];
-      if (getenv("BS_DEBUG") && o.list_n > n + 1)
+      if (dbg && o.list_n > n + 1)
         fprintf(stderr, "[bs] IMPOSSIBLE list: round %ld w=%d seed=%d status=%d consistent=%d list_n=%ld steps=%ld log=%ld thief=%d\n",
                 (long)rounds, w, o.seed, o.status, o.consistent, (long)o.list_n, (long)o.steps, (long)o.log_n, o.thief);
       if (o.status == ST_WATCHDOG)
@@ -1848,7 +1865,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         return fail(ctx, BS_ERR_NOMEM, "region grow (speculative): round pool exhausted");
       max_waves = std::max(1, max_waves / 8);
     }
-    if (getenv("BS_DEBUG")) {
+    if (dbg) {
       int cnt[6] = {0, 0, 0, 0, 0, 0}, cons = 0, pcons = 0;
       int64_t maxsteps = 0, sumsteps = 0, maxlist = 0;
       for (int w = 0; w < ncand; w++) {
@@ -1860,6 +1877,12 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       }
       for (int w = 0; w < npend; w++)
         pcons += h_pend[w].consistent;
+      int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < ncand; w++)
+        if (h_out[w].status == ST_DONE && !h_out[w].consistent)
+          why[h_out[w].pad4 & 7]++;
+      fprintf(stderr, "[bs]   inconsistent new planes by failed test (1 seed row, 2 list, 4 log; sums): 1:%d 2:%d 3:%d 4:%d 5:%d 6:%d 7:%d\n",
+              why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
       fprintf(stderr,
               "[bs] round %ld F=%d ncand_all=%d grown=%d done=%d (consistent %d) failed0=%d nomem=%d stolen=%d "
               "pending=%d (consistent %d) first_bad=%d new_min=%d maxsteps=%ld sumsteps=%ld maxlist=%ld passes=%ld\n",
@@ -1898,7 +1921,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         }
         if (o.seed < first_bad) {
           finals++;
-          if (getenv("BS_DEBUG") && o.keep)
+          if (dbg && o.keep)
             fprintf(stderr, "[bs]   commit seed=%d n=%ld log=%ld steps=%ld from=%s round=%ld first_bad=%d\n", o.seed,
                     (long)o.list_n, (long)o.log_n, (long)o.steps, take_p ? "pending" : "new", (long)rounds, first_bad);
           rc = commit_plane(o, src);
