@@ -524,34 +524,51 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
 __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec, int quads, int K,
                                  int64_t n, int32_t F, const int32_t* __restrict__ prio, const uint8_t* __restrict__ ps,
                                  const int32_t* __restrict__ omega, int32_t* min_idx,
-                                 unsigned long long* __restrict__ cand_out, int32_t* cand_count, uint8_t* __restrict__ bcand)
+                                 unsigned long long* __restrict__ cand_out, int32_t* cand_count, uint8_t* __restrict__ bcand,
+                                 int sub)
 {
   // A 256-position group whose points can never seed again -- incomplete static masks, points
   // owned by a FINAL attempt (owner < F; F only grows) -- is skipped for the rest of the call: in the late
   // rounds of a large cloud almost every group is, and the scan costs microseconds instead of a pass over n.
-  if (!bcand[blockIdx.x])
-    return;
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool c = false, alive = false;
-  const uint32_t full = (K - 1 >= 32) ? 0xffffffffu : ((1u << (K - 1)) - 1u);
-  const int32_t pi = i < n ? prio[i] : 0;
-  if (i < n && hmask[i] == full) {
-    const int32_t oi = omega[i];
-    alive = !(oi < F);  // (a pending plane's seed counts as alive: the plane can still be dropped)
-    if (pi >= F && oi >= pi && !ps[i]) {
-      c = true;
-      const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
-      for (int t = 1; t < K; t++)
-        c = c && omega[row[t]] >= pi;
-    }
+  // A workgroup owns `sub` (<= 64) consecutive groups and visits the live ones (one workgroup per group was
+  // 195 k block launches = 0.14 ms per scan at 50 M, twice per round).
+  __shared__ unsigned long long sub_mask;
+  const int64_t nb256 = (n + 255) >> 8;
+  const int64_t g0 = (int64_t)blockIdx.x * sub;
+  if (threadIdx.x < 64) {
+    const int64_t gidx = g0 + threadIdx.x;
+    const bool live = (int)threadIdx.x < sub && gidx < nb256 && bcand[gidx] != 0;
+    const unsigned long long m = ballot64(live);
+    if (threadIdx.x == 0)
+      sub_mask = m;
   }
-  const int any_alive = __syncthreads_or(alive);
-  if (threadIdx.x == 0 && !any_alive)
-    bcand[blockIdx.x] = 0;
-  if (c && min_idx)
-    atomicMin(min_idx, pi);
-  if (c && cand_out)  // sparse: appended unordered as (original index << 32 | position), sorted afterwards
-    cand_out[atomicAdd(cand_count, 1)] = ((unsigned long long)(uint32_t)pi << 32) | (uint32_t)i;
+  __syncthreads();
+  unsigned long long gm = sub_mask;
+  const uint32_t full = (K - 1 >= 32) ? 0xffffffffu : ((1u << (K - 1)) - 1u);
+  while (gm) {  // (block-uniform trip count: the barrier below is reached by every thread)
+    const int t = __ffsll(gm) - 1;
+    gm &= gm - 1;
+    const int64_t i = ((g0 + t) << 8) + threadIdx.x;
+    bool c = false, alive = false;
+    const int32_t pi = i < n ? prio[i] : 0;
+    if (i < n && hmask[i] == full) {
+      const int32_t oi = omega[i];
+      alive = !(oi < F);  // (a pending plane's seed counts as alive: the plane can still be dropped)
+      if (pi >= F && oi >= pi && !ps[i]) {
+        c = true;
+        const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
+        for (int u = 1; u < K; u++)
+          c = c && omega[row[u]] >= pi;
+      }
+    }
+    const int any_alive = __syncthreads_or(alive);
+    if (threadIdx.x == 0 && !any_alive)
+      bcand[g0 + t] = 0;
+    if (c && min_idx)
+      atomicMin(min_idx, pi);
+    if (c && cand_out)  // sparse: appended unordered as (original index << 32 | position), sorted afterwards
+      cand_out[atomicAdd(cand_count, 1)] = ((unsigned long long)(uint32_t)pi << 32) | (uint32_t)i;
+  }
 }
 
 // ---- (b) speculative plane growth: one wavefront per candidate seed -------------
@@ -1734,7 +1751,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // lowest NEW candidate sees exactly the owners this round starts from unless planes were dropped)
     if (!cand_listed) {
       BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
-      cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, nullptr, cand_raw, d_misc + 1, bcand);
+      cand_flag_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, nullptr, cand_raw, d_misc + 1, bcand, pull_sub);
       BS_HIP(ctx, hipMemcpyAsync(h_flags + 11, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
       ncand_all = h_flags[11];
@@ -1818,7 +1835,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // same pass, the candidate list of the next round
     const int32_t init2[2] = {0, INF};
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 1, init2, sizeof init2, hipMemcpyHostToDevice, st));
-    cand_flag_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, d_misc + 2, cand_raw, d_misc + 1, bcand);
+    cand_flag_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, d_misc + 2, cand_raw, d_misc + 1, bcand, pull_sub);
     // (d_misc[1] = number of candidates listed, d_misc[2] = the lowest one: one copy into the page-locked flags)
     BS_HIP(ctx, hipMemcpyAsync(h_flags + 8, d_misc + 1, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (v3_pending) {  // validate3's verdicts (PlaneOut.v3ok, the refusal counter) are read below
