@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--k", type=int, default=0, help="neighbour-list length (0 = workload default)")
     ap.add_argument("--rg-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-audit", action="store_true",
+                    help="skip the untimed extra pass that replays every plane attempt against the final owners")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path "
                          "with several ranks sharing one GPU)")
@@ -172,7 +174,8 @@ def roofline_block(n, k, stage, launches_per_step, rg_mode, workload):
             "alg_bytes_per_launch": dbytes, "avg_ms": dms, "launches_per_step": lps}
 
 
-def measure_single(ctx, api, torch, dev, name, k_override, rg_mode, steps, warmup, fence, world=1, all_reduce_max=None):
+def measure_single(ctx, api, torch, dev, name, k_override, rg_mode, steps, warmup, fence, world=1, all_reduce_max=None,
+                   audit=False):
     """Whole path on one GPU per rank (bs_segment_dev), inputs resident in HBM."""
     xyz, k = make_cloud(name)
     if k_override:
@@ -206,6 +209,17 @@ def measure_single(ctx, api, torch, dev, name, k_override, rg_mode, steps, warmu
     tm = ctx.timings()
     for kk in stage:
         stage[kk] /= max(steps, 1)
+    audit_res = None
+    if audit:  # one more, UNTIMED pass with the replay certificate switched on (bs_set_audit)
+        ctx.set_audit(True)
+        try:
+            step()
+            ta = ctx.timings()
+        finally:
+            ctx.set_audit(False)
+        audit_res = {"attempts_replayed": ta["audit_attempts"], "mismatches": ta["audit_mismatches"], "ms": ta["audit_ms"],
+                     "note": "every plane attempt grown again against the final owners, lists / normals / centres compared "
+                             "bit for bit; untimed extra pass"}
     res = {"workload": name, "points": n, "k": k, "steps": steps, "warmup": warmup,
            "value": world * n * steps / elapsed / 1e6, "unit": "Mpoints/s", "ms_per_step": elapsed / max(steps, 1) * 1e3,
            "stages_ms": stage, "rg_rounds": tm["rg_rounds"], "largest_plane": tm["largest_plane"],
@@ -214,6 +228,8 @@ def measure_single(ctx, api, torch, dev, name, k_override, rg_mode, steps, warmu
            "end_to_end_alg_GBps": n * (88 + 8 * k) / (elapsed / max(steps, 1)) / 1e9,
            "roofline": roofline_block(n, k, stage, launches / max(steps, 1), rg_mode, name),
            "radius_mm": params.radius, "max_nn": params.max_nn}
+    if audit_res:
+        res["audit"] = audit_res
     del d_xyz, d_neigh, d_normals, d_plane
     torch.cuda.empty_cache()
     return res, xyz, k
@@ -335,7 +351,8 @@ def main():
     out = None
     if world == 1 or args.replicas:
         res, xyz, k = measure_single(ctx, api, torch, dev, args.workload, args.k, args.rg_mode, args.steps, args.warmup,
-                                     fence, world, all_reduce_max if world > 1 else None)
+                                     fence, world, all_reduce_max if world > 1 else None,
+                                     audit=(world == 1 and not args.no_audit and args.rg_mode in (0, 2)))
         if rank == 0:
             out = dict(common)
             out.update({"value": res["value"], "ms_per_step": res["ms_per_step"], "scaling": "weak",
@@ -347,13 +364,16 @@ def main():
                                    "parallelism": "1 GPU, whole path" if world == 1 else f"{world} independent replicas"},
                         "stages_ms": res["stages_ms"], "end_to_end_alg_GBps": res["end_to_end_alg_GBps"],
                         "roofline": res["roofline"]})
+            if "audit" in res:
+                out["audit"] = res["audit"]
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.workload, xyz, k)
         del xyz
         if world == 1 and args.secondary:
             sec = []
             for name in [s for s in args.secondary.split(",") if s and s != args.workload]:
-                r2, _, _ = measure_single(ctx, api, torch, dev, name, 0, args.rg_mode, 2, 1, fence)
+                r2, _, _ = measure_single(ctx, api, torch, dev, name, 0, args.rg_mode, 2, 1, fence,
+                                          audit=(not args.no_audit and args.rg_mode in (0, 2)))
                 for drop in ("radius_mm", "max_nn"):
                     r2.pop(drop)
                 sec.append(r2)

@@ -21,7 +21,7 @@ EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "b
            "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_knn_normals_halo", "bs_region_grow", "bs_segment",
            "bs_planes_free", "bs_plane_colors", "bs_knn_normals_dev", "bs_region_grow_dev",
            "bs_segment_dev", "bs_planes_fetch", "bs_shift_to_origin_dev", "bs_plane_colors_dev",
-           "bs_selftest_center_div", "bs_selftest_forge_next", "bs_ingest_dev", "bs_grid_dims", "bs_grid_picture", "bs_grid_picture_dev"]
+           "bs_selftest_center_div", "bs_selftest_forge_next", "bs_set_audit", "bs_ingest_dev", "bs_grid_dims", "bs_grid_picture", "bs_grid_picture_dev"]
 
 
 class Params(C.Structure):
@@ -41,7 +41,8 @@ class Timings(C.Structure):
                 ("total_ms", C.c_double), ("largest_plane", C.c_int64), ("n_seed_attempts", C.c_int64),
                 ("n_fallback_queries", C.c_int64), ("rg_rounds", C.c_int64), ("grow_kernel_ms", C.c_double),
                 ("grow_kernel_launches", C.c_int64), ("grow_setup_ms", C.c_double),
-                ("validation_rejects", C.c_int64), ("forged_seed", C.c_int64), ("forged_refused", C.c_int64)]
+                ("validation_rejects", C.c_int64), ("forged_seed", C.c_int64), ("forged_refused", C.c_int64),
+                ("audit_attempts", C.c_int64), ("audit_mismatches", C.c_int64), ("audit_ms", C.c_double)]
 
 
 class BsError(RuntimeError):
@@ -91,6 +92,7 @@ def load():
                                 C.c_int32, ip, ip]
     L.bs_plane_colors_dev.argtypes = [vp, ip, C.c_int32, C.c_int64, vp]
     L.bs_selftest_forge_next.argtypes = [vp, C.c_int]
+    L.bs_set_audit.argtypes = [vp, C.c_int]
     L.bs_selftest_center_div.argtypes = [vp, ip, vp, ip, C.c_int64]
     L.bs_grid_dims.argtypes = [ip, C.c_int32, ip, ip]
     L.bs_grid_picture.argtypes = [vp, ip, C.c_int64, ip, C.c_int32, C.c_int32, dp, dp]

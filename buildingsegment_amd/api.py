@@ -220,6 +220,11 @@ class Context:
         timings()['validation_rejects'] must then be >= 1 and the result still exact."""
         self._check(self._L.bs_selftest_forge_next(self._h, int(mode)))
 
+    def set_audit(self, on=True):
+        """Replay every plane attempt against the final owners after each region grow (see bs_set_audit);
+        timings()['audit_mismatches'] must be 0."""
+        self._check(self._L.bs_set_audit(self._h, 1 if on else 0))
+
     def planes_fetch(self):
         P = Planes()
         self._check(self._L.bs_planes_fetch(self._h, C.byref(P)))

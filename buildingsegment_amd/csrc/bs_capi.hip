@@ -318,6 +318,14 @@ int bs_selftest_forge_next(bs_ctx* ctx, int mode)
   return BS_OK;
 }
 
+int bs_set_audit(bs_ctx* ctx, int on)
+{
+  if (!ctx)
+    return BS_ERR_INVALID;
+  ctx->audit = on ? 1 : 0;
+  return BS_OK;
+}
+
 int bs_planes_fetch(bs_ctx* ctx, bs_planes* out)
 {
   if (!ctx || !out)

@@ -161,6 +161,7 @@ struct bs_ctx {
   int64_t rg_n = 0;
   bool rg_valid = false;
   int forge_mode = 0;  // bs_selftest_forge_next
+  int audit = 0;       // bs_set_audit
   hipStream_t side = nullptr;  // second stream of the grower (validate3 beside the owner passes)
   hipEvent_t sev[2] = {nullptr, nullptr};
   // 2-D raster scratch (bs_raster.hip)

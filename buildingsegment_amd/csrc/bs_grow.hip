@@ -281,6 +281,9 @@ int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_no
     ctx->tm.validation_rejects = 0;
     ctx->tm.forged_seed = -1;
     ctx->tm.forged_refused = 0;
+    ctx->tm.audit_attempts = -1;  // the sequential baseline needs no audit
+    ctx->tm.audit_mismatches = 0;
+    ctx->tm.audit_ms = 0.0;
   }
   return BS_OK;
 }

@@ -53,6 +53,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <chrono>
 #include <vector>
 
 #include "bs_centerdiv.h"
@@ -554,7 +555,7 @@ __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int4*
     if (i < n && hmask[i] == full) {
       const int32_t oi = omega[i];
       alive = !(oi < F);  // (a pending plane's seed counts as alive: the plane can still be dropped)
-      if (pi >= F && oi >= pi && !ps[i]) {
+      if (pi >= F && oi >= pi && !(ps && ps[i])) {  // (ps == nullptr: the audit lists committed seeds too)
         c = true;
         const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
         for (int u = 1; u < K; u++)
@@ -1401,6 +1402,51 @@ __global__ __launch_bounds__(VT) void validate2_kernel(PlaneOut* out, int ncand,
   }
 }
 
+// ---- audit (bs_set_audit): replayed attempt vs. what was committed ---------------------------
+// out[w] is the attempt of seed out[w].seed grown again against the FINAL owners (no speculation).
+// A committed seed must reproduce its list entry by entry (the replay holds positions, the committed
+// list original indices), its normal and its centre bit for bit; any other attempt must be one the
+// reference rolls back (list_n <= th_count).  stats[0] = mismatches, stats[1] = committed planes met.
+__global__ __launch_bounds__(VT) void audit_compare_kernel(const PlaneOut* __restrict__ out, int na,
+                                                           const int32_t* __restrict__ pool, const int32_t* __restrict__ prio,
+                                                           const int32_t* __restrict__ seeds, const PlaneRec* __restrict__ planes,
+                                                           int np, const int32_t* __restrict__ lists, int64_t th_count, int* stats)
+{
+  const int w = blockIdx.x;
+  if (w >= na)
+    return;
+  const PlaneOut o = out[w];
+  int lo = 0, hi = np;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (seeds[mid] < o.seed)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const bool committed = lo < np && seeds[lo] == o.seed;
+  bool bad = o.status != ST_DONE;
+  if (!bad && committed) {
+    const PlaneRec r = planes[lo];
+    bad = r.list_n != o.list_n || r.center[0] != o.center[0] || r.center[1] != o.center[1] || r.center[2] != o.center[2] ||
+          __double_as_longlong(r.normal[0]) != __double_as_longlong(o.normal[0]) ||
+          __double_as_longlong(r.normal[1]) != __double_as_longlong(o.normal[1]) ||
+          __double_as_longlong(r.normal[2]) != __double_as_longlong(o.normal[2]);
+    if (!bad)
+      for (int64_t t = threadIdx.x; t < o.list_n; t += VT)
+        bad = bad || lists[r.list_off + t] != prio[pool[o.list_off + t]];
+  } else if (!bad) {
+    bad = o.list_n > th_count;
+  }
+  const int b = __syncthreads_or(bad);
+  if (threadIdx.x == 0) {
+    if (b)
+      atomicAdd(stats, 1);
+    if (committed)
+      atomicAdd(stats + 1, 1);
+  }
+}
+
 struct CopyDesc {
   const int32_t* src;
   int32_t* dst;
@@ -2031,6 +2077,81 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   {
     float ms = 0.f;
     ctx->tm.grow_setup_ms = hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]) == hipSuccess ? (double)ms : 0.0;
+  }
+  ctx->tm.audit_attempts = -1;
+  ctx->tm.audit_mismatches = 0;
+  ctx->tm.audit_ms = 0.0;
+  if (ctx->audit || getenv("BS_AUDIT")) {
+    // Every plane attempt that exists under the final owners, grown again without speculation (a.F = INF:
+    // an owner below the seed is final and taken, everything else is free at the seed's time) and compared
+    // with what was committed -- see bs_set_audit in include/bs_api.h.
+    const auto t0 = std::chrono::steady_clock::now();
+    BS_HIP(ctx, hipMemsetAsync(bcand, 1, nb256, st));
+    BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
+    BS_HIP(ctx, hipMemsetAsync(d_misc + 8, 0, 2 * sizeof(int32_t), st));
+    cand_flag_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(hmask, rec, quads, K, n, 0, prio, nullptr, omega, nullptr,
+                                                                              cand_raw, d_misc + 1, bcand, pull_sub);
+    BS_HIP(ctx, hipMemcpyAsync(h_flags + 11, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    BS_HIP(ctx, hipStreamSynchronize(st));
+    const int na = h_flags[11];
+    // Committed planes only ever claim their own points, so all of them replay concurrently.  An attempt the
+    // reference rolled back gave its points free again: its replay may claim points that belong to later
+    // planes (or to another rolled-back attempt), so these are replayed one at a time on clean tags.
+    std::vector<unsigned long long> hc((size_t)na), hc_sorted;
+    if (na > 0)
+      BS_HIP(ctx, hipMemcpy(hc.data(), cand_raw, sizeof(unsigned long long) * na, hipMemcpyDeviceToHost));
+    std::sort(hc.begin(), hc.end());
+    int n_committed = 0;
+    {
+      std::vector<unsigned long long> rest;
+      for (const unsigned long long c : hc) {
+        const int32_t sd = (int32_t)(c >> 32);
+        if (std::binary_search(seeds.begin(), seeds.end(), sd))
+          hc_sorted.push_back(c);
+        else
+          rest.push_back(c);
+      }
+      n_committed = (int)hc_sorted.size();
+      hc_sorted.insert(hc_sorted.end(), rest.begin(), rest.end());
+    }
+    if (na > 0)
+      BS_HIP(ctx, hipMemcpyAsync(d_cand, hc_sorted.data(), sizeof(unsigned long long) * na, hipMemcpyHostToDevice, st));
+    a.F = INF;
+    auto grow_n = [&](int off, int cnt, PlaneOut* o) {
+      if (KC == 16)
+        grow_spec_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0);
+      else
+        grow_spec_kernel<32><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0);
+    };
+    auto compare_n = [&](int cnt) {
+      audit_compare_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, prio, d_seeds, ctx->rg_planes.as<PlaneRec>(), np,
+                                               ctx->rg_list.as<int32_t>(), a.th_count, d_misc + 8);
+    };
+    for (int off = 0; off < n_committed; off += wave_cap) {
+      const int cnt = std::min(n_committed - off, wave_cap);
+      BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
+      grow_n(off, cnt, d_out);
+      compare_n(cnt);
+      reset_tags_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, rec, quads, K);
+    }
+    for (int off = n_committed; off < na; off += wave_cap) {
+      const int cnt = std::min(na - off, wave_cap);
+      BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
+      for (int i = 0; i < cnt; i++) {
+        grow_n(off + i, 1, d_out + i);
+        reset_tags_kernel<<<1, VT, 0, st>>>(d_out + i, 1, pool.base, rec, quads, K);
+      }
+      compare_n(cnt);  // (the lists are still in the pool)
+    }
+    BS_HIP(ctx, hipMemcpyAsync(h_flags + 12, d_misc + 8, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    BS_HIP(ctx, hipStreamSynchronize(st));
+    BS_HIP(ctx, hipGetLastError());
+    ctx->tm.audit_attempts = na;
+    ctx->tm.audit_mismatches = (int64_t)h_flags[12] + (h_flags[13] != np ? 1 : 0);
+    ctx->tm.audit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (dbg || ctx->tm.audit_mismatches)
+      fprintf(stderr, "[bs] audit: %d attempts replayed, %d of %d committed planes met, %d mismatches, %.1f ms\n", na, h_flags[13], np,
+              h_flags[12], ctx->tm.audit_ms);
   }
   return BS_OK;
 }

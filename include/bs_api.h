@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BS_API_VERSION 2
+#define BS_API_VERSION 3
 
 typedef enum bs_status {
   BS_OK = 0,
@@ -94,6 +94,9 @@ typedef struct bs_timings {
                                  refused planes are grown again, the result stays exact */
   int64_t forged_seed;        /* seed of the plane bs_selftest_forge_next corrupted, -1 if none */
   int64_t forged_refused;     /* 1 if the validation refused exactly that plane */
+  int64_t audit_attempts;     /* bs_set_audit: plane attempts replayed against the final owners (-1: audit off) */
+  int64_t audit_mismatches;   /* ... of which differ from what was committed (must be 0) */
+  double audit_ms;            /* time of the replay + comparison (not part of grow_ms / total_ms) */
 } bs_timings;
 
 typedef struct bs_ctx bs_ctx;
@@ -237,6 +240,18 @@ int bs_selftest_center_div(bs_ctx* ctx, const int32_t* c, const uint32_t* n, int
  * validation must refuse the plane (bs_timings.forged_refused == 1, forged_seed names it); it is
  * then grown again and the final result is still exact. */
 int bs_selftest_forge_next(bs_ctx* ctx, int mode);
+
+/* Audit mode (off by default; also switched on by the environment variable BS_AUDIT=1).  After a
+ * speculative region grow (rg_mode 0 / 2) every plane attempt that exists under the FINAL owners -- the
+ * committed planes and the attempts the reference rolls back (my_function.cpp:199) -- is grown once more,
+ * all of them concurrently, with the production step engine but WITHOUT speculation: a point is taken iff
+ * its final owner is an earlier attempt, nothing is assumed, nothing can be stolen.  Every Broad() decision
+ * of every plane is thereby re-made against the state the sequential reference has at that plane's time;
+ * the replayed lists must equal the committed ones entry by entry, in order, with bit-equal normal and
+ * centre, and an attempt that was not committed must end at or below the commit threshold.  Together with
+ * the owner equations (BS_VERIFY=1) this certifies the result of the speculation by induction over the
+ * seed index.  Costs about one extra pass of the longest plane; bs_timings.audit_* report it. */
+int bs_set_audit(bs_ctx* ctx, int on);
 
 /* Copy the plane records of the last region-grow on this context to the host. */
 int bs_planes_fetch(bs_ctx* ctx, bs_planes* planes);

@@ -82,8 +82,14 @@ def test_fullsize_digests_and_properties(gpu_ctx, workload):
     assert sha(xyz) == gold["xyz"], "synthetic generator drifted: regenerate tests/golden/digests.json"
     print(f"\n[{workload}] cloud {time.time() - t0:.1f}s", flush=True)
     t0 = time.time()
-    neigh, normals, plane_idx, planes = gpu_ctx.segment(xyz, api.default_params(k=k))
+    gpu_ctx.set_audit(True)  # replay of every plane attempt against the final owners (bs_set_audit)
+    try:
+        neigh, normals, plane_idx, planes = gpu_ctx.segment(xyz, api.default_params(k=k))
+    finally:
+        gpu_ctx.set_audit(False)
     tm = gpu_ctx.timings()
+    assert tm["audit_mismatches"] == 0 and tm["audit_attempts"] == tm["n_seed_attempts"], tm
+    print(f"[{workload}] audit: {tm['audit_attempts']} attempts replayed in {tm['audit_ms']:.0f} ms, 0 mismatches", flush=True)
     print(f"[{workload}] segment (host buffers) {time.time() - t0:.1f}s, device {tm['total_ms']:.0f} ms, "
           f"rounds {tm['rg_rounds']}, planes {len(planes)}", flush=True)
     # digests vs the CPU oracle's
@@ -122,8 +128,14 @@ def test_urban_200m_on_one_gpu_properties(gpu_ctx):
     assert len(xyz) == 200_000_000 and k == 16
     print(f"\n[urban_200m] cloud {time.time() - t0:.1f}s", flush=True)
     t0 = time.time()
-    neigh, normals, plane_idx, planes = gpu_ctx.segment(xyz, api.default_params(k=k))
+    gpu_ctx.set_audit(True)  # no oracle at this size: the replay certificate stands in for the digests
+    try:
+        neigh, normals, plane_idx, planes = gpu_ctx.segment(xyz, api.default_params(k=k))
+    finally:
+        gpu_ctx.set_audit(False)
     tm = gpu_ctx.timings()
+    assert tm["audit_mismatches"] == 0 and tm["audit_attempts"] == tm["n_seed_attempts"], tm
+    print(f"[urban_200m] audit: {tm['audit_attempts']} attempts replayed in {tm['audit_ms']:.0f} ms, 0 mismatches", flush=True)
     print(f"[urban_200m] segment (host buffers) {time.time() - t0:.1f}s, device {tm['total_ms']:.0f} ms = "
           f"{len(xyz) / tm['total_ms'] / 1e3:.0f} Mpoints/s, rounds {tm['rg_rounds']}, planes {len(planes)}", flush=True)
     assert len(planes) > 5000 and int((plane_idx > 0).sum()) > 150_000_000

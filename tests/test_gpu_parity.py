@@ -408,3 +408,59 @@ def test_validation_rejects_a_forged_plane(gpu_ctx, oracle, mode):
     assert np.array_equal(np.stack([q.center for q in planes]), opl["center"])
     gpu_ctx.region_grow(xyz, normals, neigh, p)  # the hook is one-shot
     assert gpu_ctx.timings()["forged_seed"] == -1
+
+
+def test_audit_replays_every_plane_attempt(gpu_ctx, oracle):
+    """bs_set_audit: after the speculative grow, every plane attempt that exists under the final owners is grown
+    again WITHOUT speculation (owner below the seed = taken, everything else free at the seed's time) and must
+    reproduce the committed list entry by entry, normal and centre bit for bit; attempts that were not committed
+    must end at or below the commit threshold.  The number of attempts found that way equals the number the
+    speculative rounds finalised.  (my_function.cpp:180-258)"""
+    from buildingsegment_amd import api, synth
+    gpu_ctx.set_audit(True)
+    try:
+        for xyz, k in ((synth.plane_cube(), 15), (synth.facade(400, seed=9), 16), (synth.urban(300_000, seed=8), 16),
+                       (synth.uniform(20_000, seed=3), 8)):
+            xyz = np.ascontiguousarray(xyz)
+            neigh, normals, plane_idx, planes = gpu_ctx.segment(xyz, api.default_params(k=k))
+            tm = gpu_ctx.timings()
+            assert tm["audit_attempts"] == tm["n_seed_attempts"] >= len(planes), tm
+            assert tm["audit_mismatches"] == 0, tm
+    finally:
+        gpu_ctx.set_audit(False)
+    gpu_ctx.segment(np.ascontiguousarray(synth.plane_cube()), api.default_params(k=15))
+    assert gpu_ctx.timings()["audit_attempts"] == -1  # off again
+
+
+AUDIT_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from buildingsegment_amd import api, synth
+ctx = api.Context(0)
+ctx.set_audit(True)
+xyz = np.ascontiguousarray(synth.plane_cube()[:40000])
+p = api.default_params(k=15)
+ctx.segment(xyz, p)
+clean = ctx.timings()
+ctx.selftest_forge_next(2)
+ctx.segment(xyz, p)
+tm = ctx.timings()
+print("RESULT", clean["audit_mismatches"], tm["forged_seed"], tm["forged_refused"], tm["audit_mismatches"])
+"""
+
+
+def test_audit_catches_what_a_disabled_validator_lets_through():
+    """With validate3 switched off (developer switch BS_NO_VALIDATE3) a plane whose reported normal was forged by
+    one ulp is committed; the audit's replay must flag it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BS_NO_VALIDATE3="1")
+    out = subprocess.run([sys.executable, "-c", AUDIT_CHILD, root], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    clean_mis, forged_seed, forged_refused, mis = (int(v) for v in line[1:])
+    assert clean_mis == 0
+    assert forged_seed >= 0 and forged_refused == 0, "the forgery did not get past the (disabled) validator"
+    assert mis >= 1, "the audit did not notice the forged plane"

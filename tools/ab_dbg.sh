@@ -3,7 +3,7 @@
 wl=$1; shift
 export BS_CLOUD_CACHE=/tmp
 for lib in "$@"; do
-  BS_DEBUG=1 BS_LIB_PATH=$PWD/$lib python bench.py --workload $wl --steps 1 --warmup 1 --secondary= --no-cpu-baseline --concurrent 0 2> /tmp/ab_dbg.err | python -c "
+  BS_DEBUG=1 BS_LIB_PATH=$PWD/$lib python bench.py --workload $wl --steps 1 --warmup 1 --secondary= --no-cpu-baseline --no-audit --concurrent 0 2> /tmp/ab_dbg.err | python -c "
 import sys,json,re
 d=json.loads(sys.stdin.readline())
 err=open('/tmp/ab_dbg.err').read()

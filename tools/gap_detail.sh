@@ -2,7 +2,7 @@
 # tools/gap_detail.sh <workload> <round>: every kernel between the end of growth launch <round> and the next one (last pass)
 export TMPDIR=/tmp BS_CLOUD_CACHE=/tmp
 mkdir -p gpurun_out/r02; rm -rf gpurun_out/r02/kt
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/kt -- python3 bench.py --workload $1 --steps 1 --warmup 1 --secondary= --no-cpu-baseline --concurrent 0 > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/kt -- python3 bench.py --workload $1 --steps 1 --warmup 1 --secondary= --no-cpu-baseline --no-audit --concurrent 0 > /dev/null 2>&1 || exit 1
 python3 - <<PY
 import csv, glob, re
 f = glob.glob('gpurun_out/r02/kt/*/*kernel_trace.csv')[0]

@@ -3,7 +3,7 @@
 wl=$1; tag=$2
 export TMPDIR=/tmp BS_CLOUD_CACHE=/tmp
 mkdir -p gpurun_out/r02; rm -rf gpurun_out/r02/ks_tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02/ks_tmp -- python3 bench.py --workload $wl --steps 2 --warmup 1 --secondary= --no-cpu-baseline --concurrent 0 > gpurun_out/r02/ks_${tag}.json 2> gpurun_out/r02/ks_${tag}.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02/ks_tmp -- python3 bench.py --workload $wl --steps 2 --warmup 1 --secondary= --no-cpu-baseline --no-audit --concurrent 0 > gpurun_out/r02/ks_${tag}.json 2> gpurun_out/r02/ks_${tag}.err || exit 1
 cp gpurun_out/r02/ks_tmp/*/*kernel_stats.csv gpurun_out/r02/ks_${tag}.csv
 rm -rf gpurun_out/r02/ks_tmp
 python3 - <<PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # histogram of pull_pass_kernel durations for one pass of a workload (rocprofv3 kernel trace)
 export TMPDIR=/tmp BS_CLOUD_CACHE=/tmp
-rm -rf gpurun_out/r02/kt; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/kt -- python3 bench.py --workload $1 --steps 1 --warmup 0 --secondary= --no-cpu-baseline > /dev/null 2>&1
+rm -rf gpurun_out/r02/kt; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/kt -- python3 bench.py --workload $1 --steps 1 --warmup 0 --secondary= --no-cpu-baseline --no-audit > /dev/null 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob('gpurun_out/r02/kt/*/*kernel_trace.csv')[0]

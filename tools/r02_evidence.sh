@@ -4,7 +4,7 @@
 #   facade_1m: SQ instruction-mix passes, in-kernel phase probes.  Output: gpurun_out/r02/ev/
 export TMPDIR=/tmp BS_CLOUD_CACHE=/tmp
 E=gpurun_out/r02/ev; mkdir -p $E
-B="--steps 2 --warmup 1 --secondary= --no-cpu-baseline --concurrent 0"
+B="--steps 2 --warmup 1 --secondary= --no-cpu-baseline --no-audit --concurrent 0"
 for wl in ${WORKLOADS:-facade_1m urban_10m urban_50m}; do
   rm -rf $E/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $E/tmp -- python3 bench.py --workload $wl $B > $E/ks_$wl.json 2> $E/ks_$wl.err || exit 1
   cp $E/tmp/*/*kernel_stats.csv $E/${wl}_kernel_stats.csv; echo "kernel stats $wl done"
@@ -32,7 +32,7 @@ done
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM" "SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES"; do
   i=$((i+1)); rm -rf $E/tmp
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $E/tmp -- python3 bench.py --workload facade_1m --steps 1 --warmup 0 --secondary= --no-cpu-baseline --concurrent 0 > /dev/null 2> $E/sq$i.err || exit 1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $E/tmp -- python3 bench.py --workload facade_1m --steps 1 --warmup 0 --secondary= --no-cpu-baseline --no-audit --concurrent 0 > /dev/null 2> $E/sq$i.err || exit 1
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$E/tmp/*/*counter_collection.csv")[0]

@@ -3,7 +3,7 @@
 # growth kernel ms, the gap until the next growth launch (validation, owner passes, host round trips), owner passes in it
 export TMPDIR=/tmp BS_CLOUD_CACHE=/tmp
 mkdir -p gpurun_out/r02; rm -rf gpurun_out/r02/kt
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/kt -- python3 bench.py --workload $1 --steps 1 --warmup 1 --secondary= --no-cpu-baseline --concurrent 0 > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/kt -- python3 bench.py --workload $1 --steps 1 --warmup 1 --secondary= --no-cpu-baseline --no-audit --concurrent 0 > /dev/null 2>&1 || exit 1
 python3 - <<PY
 import csv, glob
 f = glob.glob('gpurun_out/r02/kt/*/*kernel_trace.csv')[0]

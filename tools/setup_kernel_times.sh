@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel time of a few setup kernels via rocprofv3 for a lib
 lib=$1; wl=$2
-export TMPDIR=/tmp; rm -rf gpurun_out/pk; BS_LIB_PATH=$PWD/$lib rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pk -- python3 bench.py --workload $wl --steps 1 --warmup 1 --secondary "" --no-cpu-baseline > /dev/null 2>&1
+export TMPDIR=/tmp; rm -rf gpurun_out/pk; BS_LIB_PATH=$PWD/$lib rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pk -- python3 bench.py --workload $wl --steps 1 --warmup 1 --secondary "" --no-cpu-baseline --no-audit > /dev/null 2>&1
 python3 - <<PY
 import csv,glob,re
 f=glob.glob('gpurun_out/pk/*/*kernel_stats.csv')[0]
