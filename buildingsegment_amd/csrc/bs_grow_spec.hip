@@ -1781,6 +1781,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   int refused_rounds = 0;
   int forge_mode = ctx->forge_mode;
   ctx->forge_mode = 0;
+  const int lds_pad = getenv("BS_GROW_LDS_PAD") ? atoi(getenv("BS_GROW_LDS_PAD")) : 0;  // experiment: unused dynamic LDS lowers the occupancy
   const bool dbg = getenv("BS_DEBUG") != nullptr;  // (not once per attempt: 158 k of them in a first round)
   const bool do_validate3 = getenv("BS_NO_VALIDATE3") == nullptr;  // developer A/B switch
   BS_HIP(ctx, hipMemsetAsync(d_misc + 4, 0, 3 * sizeof(int), st));  // [4] refused planes, [5] forged seed + 1, [6] forged one refused
@@ -1844,9 +1845,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       // chained planes (the facade) the re-growth only repeats work the next round does anyway (-23 %).
       const int rml = (ncand >= retry_big_round && !retry_env) ? 0x7fffffff : retry_max_list;
       if (KC == 16)
-        grow_spec_kernel<16><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml);
+        grow_spec_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml);
       else
-        grow_spec_kernel<32><<<ncand, 64, 0, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml);
+        grow_spec_kernel<32><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml);
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
@@ -2134,14 +2135,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       compare_n(cnt);
       reset_tags_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, rec, quads, K);
     }
-    for (int off = n_committed; off < na; off += wave_cap) {
-      const int cnt = std::min(na - off, wave_cap);
+    for (int i = n_committed; i < na; i++) {  // one at a time, each with the whole pool to itself
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
-      for (int i = 0; i < cnt; i++) {
-        grow_n(off + i, 1, d_out + i);
-        reset_tags_kernel<<<1, VT, 0, st>>>(d_out + i, 1, pool.base, rec, quads, K);
-      }
-      compare_n(cnt);  // (the lists are still in the pool)
+      grow_n(i, 1, d_out);
+      compare_n(1);
+      reset_tags_kernel<<<1, VT, 0, st>>>(d_out, 1, pool.base, rec, quads, K);
     }
     BS_HIP(ctx, hipMemcpyAsync(h_flags + 12, d_misc + 8, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));

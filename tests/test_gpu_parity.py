@@ -358,7 +358,7 @@ def test_fuzz_negative_coordinates_and_noisy_normals():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_parity.py"), "--cases", "40", "--seed", "4242"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_parity.py"), "--cases", "40", "--seed", "4242", "--audit"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "40 cases, 0 mismatches" in out.stdout

@@ -58,12 +58,16 @@ def main():
     ap.add_argument("--log", default="")
     ap.add_argument("--dump", default="", help="directory for the inputs of failing cases")
     ap.add_argument("--only", type=int, default=-1, help="run just this case of the sequence (the others are only drawn)")
+    ap.add_argument("--audit", action="store_true",
+                    help="also switch on the replay certificate (bs_set_audit) and count its mismatches as failures")
     ap.add_argument("--repeat", type=int, default=1,
                     help="device runs per case and mode: exposes timing-dependent (nondeterministic) mismatches")
     args = ap.parse_args()
     from buildingsegment_amd import api
     from oracle import oracle as O
     ctx = api.Context(0)
+    if args.audit:
+        ctx.set_audit(True)
     rng = np.random.default_rng(args.seed)
     log = open(args.log, "a") if args.log else sys.stdout
     bad = 0
@@ -105,6 +109,10 @@ def main():
                 continue
             if mode == 2:
                 rounds = ctx.timings()["rg_rounds"]
+                tma = ctx.timings()
+                if args.audit and (tma["audit_mismatches"] != 0 or tma["audit_attempts"] != tma["n_seed_attempts"]):
+                    ok = False
+                    why += f" audit:{tma['audit_mismatches']}_mismatches_of_{tma['audit_attempts']}_attempts(finalised:{tma['n_seed_attempts']})"
             okm = np.array_equal(pi, opi) and len(planes) == len(opl["id"])
             if okm and planes:
                 okm = (np.array_equal(np.concatenate([q.pointIdx for q in planes]), opl["point_idx"])
