@@ -182,7 +182,7 @@ void bs_destroy(bs_ctx* c)
   bs::DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->cub_tmp, &c->uniq_keys,
                         &c->uniq_cnt, &c->misc, &c->table, &c->spts, &c->slocal, &c->fb_list, &c->d_xyz_h,
                         &c->d_neigh_h, &c->d_normals_h, &c->d_plane_h, &c->seg_neigh, &c->seg_normals,
-                        &c->rg_list, &c->rg_stack, &c->rg_planes, &c->rg_stats, &c->rg_aux, &c->rg_pstore, &c->rg_rec, &c->rg_radj, &c->rg_roff, &c->rg_geo, &c->rg_gs, &c->seg_npos,
+                        &c->rg_list, &c->rg_stack, &c->rg_planes, &c->rg_stats, &c->rg_aux, &c->rg_pstore, &c->rg_rec, &c->rg_radj, &c->rg_roff, &c->rg_geo, &c->rg_gs, &c->rg_disp, &c->seg_npos,
                         &c->rs_keys_in, &c->rs_keys_out, &c->rs_vals_in, &c->rs_vals_out, &c->rs_cnt, &c->rs_img, &c->rs_tmp};
   for (auto* b : bufs)
     b->release();

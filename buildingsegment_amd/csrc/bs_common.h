@@ -156,7 +156,7 @@ struct bs_ctx {
   // pipeline scratch (bs_segment_dev with NULL outputs)
   bs::DevBuf seg_neigh, seg_normals;
   // region-grow state
-  bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec, rg_radj, rg_roff, rg_geo, rg_gs;
+  bs::DevBuf rg_list, rg_stack, rg_planes, rg_stats, rg_aux, rg_pstore, rg_rec, rg_radj, rg_roff, rg_geo, rg_gs, rg_disp;
   bs::HostBuf rg_hout;  // PlaneOut[wave_cap + MAX_PENDING] + a few scalars, page-locked
   int64_t rg_n = 0;
   bool rg_valid = false;

@@ -99,6 +99,7 @@ struct PlaneOut {
   int32_t seed_pos;    // position of the seed (seed itself is the ORIGINAL index: the priority)
   int32_t v3ok;        // validate3 (runs beside the owner passes on a second stream): state reproducible from the list
   int32_t pad4;
+  int64_t t_start, t_end;  // wall_clock64() (100 MHz) at the wave's start and end: diagnostics (BS_DEBUG)
 };
 
 struct Pool {
@@ -678,19 +679,22 @@ constexpr int RETRY_MAX_LIST = 16384;  // ... as long as little work is thrown a
 template <int KC>
 __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigned long long* __restrict__ cand, int ncand,
                                                        int4* rec, int32_t* dead, Pool pool,
-                                                       PlaneOut* __restrict__ out, int64_t step_cap, int retry_max_list)
+                                                       PlaneOut* __restrict__ out, int64_t step_cap, int retry_max_list,
+                                                       const uint32_t* __restrict__ order)
 {
   __shared__ __attribute__((aligned(16))) int lds_stack[LDS_STACK * KC];
   constexpr int Q = RecLayout<KC>::QUADS;
   constexpr int NG = 64 / KC;
-  const int w = blockIdx.x;
-  if (w >= ncand)
+  if ((int)blockIdx.x >= ncand)
     return;
+  // attempts are numbered by seed (w), dispatched in the order the host chose (see dispatch_key_kernel)
+  const int w = order ? (int)(order[blockIdx.x] & (MAX_WAVES - 1)) : (int)blockIdx.x;
   const int lane = threadIdx.x;
   const int g = lane / KC, j = lane % KC;
   const unsigned long long gmask0 = (KC == 32) ? 0xffffffffull : 0xffffull;
   const int K = a.K, nc = K - 1;
   const bool act = j < nc;
+  const int64_t t_start = (int64_t)wall_clock64();
   const int32_t seed = (int32_t)(cand[w] >> 32);         // original index: what claims and owners are compared by
   const int32_t seed_s = (int32_t)(uint32_t)cand[w];     // position: where the seed's record lives
   Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
@@ -1084,6 +1088,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
     o.seed_pos = seed_s;
     o.v3ok = 1;
     o.pad4 = 0;
+    o.t_start = t_start;
+    o.t_end = (int64_t)wall_clock64();
     out[w] = o;
   }
 }
@@ -1487,6 +1493,39 @@ __global__ void label_kernel(const int32_t* __restrict__ owner, int64_t n, const
   plane_idx[dst] = 1 + lo;
 }
 
+// ---- dispatch order of a big round ------------------------------------------------------------
+// A round lasts as long as its longest plane, and a workgroup starts when a slot is free: with 158 k attempts
+// queued in seed order the five longest planes of the 50 M cloud's first round started 13-16 ms late, behind
+// attempts that sit INSIDE a plane another, lower seed is growing (they grow until its front reaches them:
+// 115 us of slot time on average, 45 s of wave time in total over 2 560 slots).  The seed of a plane is the
+// lowest candidate inside it, so the lowest candidate of a tile of positions (Morton order: a compact piece of
+// space) is probably a real seed: those go first -- tiles of 2^16 positions, then of 2^12 -- and the rest
+// follows in seed order.  Only the dispatch order changes; the attempts keep their numbers (w = rank by seed).
+constexpr int TILE1 = 12, TILE2 = 16;
+__global__ void tile_min_kernel(const unsigned long long* __restrict__ cand, int ncand, unsigned long long* __restrict__ tmin1,
+                                unsigned long long* __restrict__ tmin2)
+{
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= ncand)
+    return;
+  const unsigned long long c = cand[w];
+  const uint32_t pos = (uint32_t)c;
+  atomicMin(&tmin1[pos >> TILE1], c);
+  atomicMin(&tmin2[pos >> TILE2], c);
+}
+
+__global__ void dispatch_key_kernel(const unsigned long long* __restrict__ cand, int ncand, const unsigned long long* __restrict__ tmin1,
+                                    const unsigned long long* __restrict__ tmin2, uint32_t* __restrict__ keys)
+{
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= ncand)
+    return;
+  const unsigned long long c = cand[w];
+  const uint32_t pos = (uint32_t)c;
+  const uint32_t lvl = tmin2[pos >> TILE2] == c ? 0u : (tmin1[pos >> TILE1] == c ? 1u : 2u);
+  keys[w] = lvl * (uint32_t)MAX_WAVES + (uint32_t)w;
+}
+
 __global__ void reset_dead_kernel(const unsigned long long* __restrict__ cand, int ncand, int32_t* __restrict__ dead)
 {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1606,6 +1645,14 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   BS_HIP(ctx, ctx->rg_gs.reserve(sizeof(int4) * 3 * (size_t)(n + 1)));  // compact geometry by position (setup only)
   int4* gs = ctx->rg_gs.as<int4>();
   unsigned long long* d_cand = cand_raw + n + 64;
+  // dispatch order of big rounds: tile minima + sort keys
+  const size_t nt1 = (size_t)(n >> TILE1) + 2, nt2 = (size_t)(n >> TILE2) + 2;
+  BS_HIP(ctx, ctx->rg_disp.reserve(sizeof(unsigned long long) * (nt1 + nt2) + sizeof(uint32_t) * 2 * (size_t)wave_cap + 64));
+  unsigned long long* tmin1 = ctx->rg_disp.as<unsigned long long>();
+  unsigned long long* tmin2 = tmin1 + nt1;
+  uint32_t* dkeys_in = reinterpret_cast<uint32_t*>(tmin2 + nt2);
+  uint32_t* dkeys_out = dkeys_in + wave_cap;
+  const bool dispatch_order = getenv("BS_NO_DISPATCH_ORDER") == nullptr;  // developer A/B switch
   // positions = the search grid's cell-sorted (Morton) order of THIS cloud when it is cached on the context
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
   int32_t* pos = nullptr;
@@ -1838,6 +1885,17 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         dead_dirty = false;
       }
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
+      const uint32_t* d_order = nullptr;
+      if (dispatch_order && ncand >= 4096) {  // see dispatch_key_kernel
+        BS_HIP(ctx, hipMemsetAsync(tmin1, 0xff, sizeof(unsigned long long) * (nt1 + nt2), st));
+        tile_min_kernel<<<nblk(ncand, 256), 256, 0, st>>>(d_cand, ncand, tmin1, tmin2);
+        dispatch_key_kernel<<<nblk(ncand, 256), 256, 0, st>>>(d_cand, ncand, tmin1, tmin2, dkeys_in);
+        size_t tb = 0;
+        BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dkeys_in, dkeys_out, ncand, 0, 20, st));
+        BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
+        BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tb, dkeys_in, dkeys_out, ncand, 0, 20, st));
+        d_order = dkeys_out;
+      }
       (void)hipEventRecord(ctx->ev[6], st);
       // In-launch re-growth of a plane that lost a point: always for short lists.  For long lists only in rounds
       // with many attempts: such a round lasts as long as its longest independent plane, so a long plane that
@@ -1845,9 +1903,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       // chained planes (the facade) the re-growth only repeats work the next round does anyway (-23 %).
       const int rml = (ncand >= retry_big_round && !retry_env) ? 0x7fffffff : retry_max_list;
       if (KC == 16)
-        grow_spec_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml);
+        grow_spec_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
       else
-        grow_spec_kernel<32><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml);
+        grow_spec_kernel<32><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
@@ -1941,6 +1999,42 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       }
       for (int w = 0; w < npend; w++)
         pcons += h_pend[w].consistent;
+      {  // when did the longest attempts start and end, relative to the first wave of the launch?
+        int64_t t0 = INT64_MAX, t1 = 0;
+        std::vector<int> idx;
+        for (int w = 0; w < ncand; w++) {
+          t0 = std::min(t0, h_out[w].t_start);
+          t1 = std::max(t1, h_out[w].t_end);
+          if (h_out[w].steps > 2000)
+            idx.push_back(w);
+        }
+        std::sort(idx.begin(), idx.end(), [&](int x, int y) { return h_out[x].steps > h_out[y].steps; });
+        fprintf(stderr, "[bs]   launch span %.2f ms; longest attempts (w, steps, status, start ms, end ms, us/step):", (t1 - t0) / 1e5);
+        for (size_t q = 0; q < std::min<size_t>(idx.size(), 6); q++) {
+          const PlaneOut& o = h_out[idx[q]];
+          fprintf(stderr, " [%d %ld %d %.2f %.2f %.3f]", idx[q], (long)o.steps, o.status, (o.t_start - t0) / 1e5, (o.t_end - t0) / 1e5,
+                  (o.t_end - o.t_start) / 100.0 / (double)o.steps);
+        }
+        fprintf(stderr, "\n");
+        if (ncand > 20000) {
+          fprintf(stderr, "[bs]   start ms by w:");
+          for (int w = 0; w < ncand; w += 8192)
+            fprintf(stderr, " %d:%.2f", w, (h_out[w].t_start - t0) / 1e5);
+          double life0 = 0, lifep = 0;
+          int64_t n0 = 0, npl = 0;
+          for (int w = 0; w < ncand; w++) {
+            if (h_out[w].status == ST_FAILED0) {
+              life0 += (h_out[w].t_end - h_out[w].t_start) / 100.0;
+              n0++;
+            } else {
+              lifep += (h_out[w].t_end - h_out[w].t_start) / 100.0;
+              npl++;
+            }
+          }
+          fprintf(stderr, "\n[bs]   mean lifetime: failed0 %.1f us (%ld), others %.1f us (%ld); wave-time total %.1f ms\n", life0 / std::max<int64_t>(n0, 1),
+                  (long)n0, lifep / std::max<int64_t>(npl, 1), (long)npl, (life0 + lifep) / 1e3);
+        }
+      }
       int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int w = 0; w < ncand; w++)
         if (h_out[w].status == ST_DONE && !h_out[w].consistent)
@@ -2120,9 +2214,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     a.F = INF;
     auto grow_n = [&](int off, int cnt, PlaneOut* o) {
       if (KC == 16)
-        grow_spec_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0);
+        grow_spec_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
       else
-        grow_spec_kernel<32><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0);
+        grow_spec_kernel<32><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
     };
     auto compare_n = [&](int cnt) {
       audit_compare_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, prio, d_seeds, ctx->rg_planes.as<PlaneRec>(), np,
