@@ -1515,30 +1515,14 @@ __global__ void tile_min_kernel(const unsigned long long* __restrict__ cand, int
 }
 
 __global__ void dispatch_key_kernel(const unsigned long long* __restrict__ cand, int ncand, const unsigned long long* __restrict__ tmin1,
-                                    const unsigned long long* __restrict__ tmin2, uint32_t* __restrict__ keys,
-                                    const int4* __restrict__ rec, int quads, double th, double cos_th)
+                                    const unsigned long long* __restrict__ tmin2, uint32_t* __restrict__ keys)
 {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= ncand)
     return;
   const unsigned long long c = cand[w];
   const uint32_t pos = (uint32_t)c;
-  const unsigned long long lead = tmin1[pos >> TILE1];
-  uint32_t lvl = tmin2[pos >> TILE2] == c ? 0u : (lead == c ? 1u : 2u);
-  if (lvl == 2u) {
-    // A follower that lies in the plane through its (lower) tile leader, with a compatible normal, is almost
-    // surely an interior point of the plane the leader grows: it goes last, and by then its neighbourhood is
-    // claimed and it fails at depth 0 at once instead of growing a doomed copy of the same plane.
-    const int4* rl = rec + (int64_t)(uint32_t)lead * quads;
-    const int4* rc = rec + (int64_t)pos * quads;
-    const int4 l0 = rl[0], l1 = rl[1], l2 = rl[2], c0 = rc[0], c1 = rc[1], c2 = rc[2];
-    const double lnx = __hiloint2double(l1.y, l1.x), lny = __hiloint2double(l1.w, l1.z), lnz = __hiloint2double(l2.y, l2.x);
-    const double cnx = __hiloint2double(c1.y, c1.x), cny = __hiloint2double(c1.w, c1.z), cnz = __hiloint2double(c2.y, c2.x);
-    const double dist = __builtin_fabs((double)(c0.x - l0.x) * lnx + (double)(c0.y - l0.y) * lny + (double)(c0.z - l0.z) * lnz);
-    const double dt = lnx * cnx + lny * cny + lnz * cnz;
-    if (dist <= th && dt >= cos_th)
-      lvl = 3u;
-  }
+  const uint32_t lvl = tmin2[pos >> TILE2] == c ? 0u : (tmin1[pos >> TILE1] == c ? 1u : 2u);
   keys[w] = lvl * (uint32_t)MAX_WAVES + (uint32_t)w;
 }
 
@@ -1905,7 +1889,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       if (dispatch_order && ncand >= 4096) {  // see dispatch_key_kernel
         BS_HIP(ctx, hipMemsetAsync(tmin1, 0xff, sizeof(unsigned long long) * (nt1 + nt2), st));
         tile_min_kernel<<<nblk(ncand, 256), 256, 0, st>>>(d_cand, ncand, tmin1, tmin2);
-        dispatch_key_kernel<<<nblk(ncand, 256), 256, 0, st>>>(d_cand, ncand, tmin1, tmin2, dkeys_in, rec, quads, a.th, a.cos_th);
+        dispatch_key_kernel<<<nblk(ncand, 256), 256, 0, st>>>(d_cand, ncand, tmin1, tmin2, dkeys_in);
         size_t tb = 0;
         BS_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, dkeys_in, dkeys_out, ncand, 0, 20, st));
         BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
