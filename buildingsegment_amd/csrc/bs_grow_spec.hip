@@ -100,6 +100,13 @@ struct PlaneOut {
   int32_t v3ok;        // validate3 (runs beside the owner passes on a second stream): state reproducible from the list
   int32_t pad4;
   int64_t t_start, t_end;  // wall_clock64() (100 MHz) at the wave's start and end: diagnostics (BS_DEBUG)
+  int32_t w;               // number of the attempt in its round (rank by seed)
+  int32_t pad5;
+};
+
+// what the host's merge looks at after a round: everything but the attempts that failed at depth 0 or gave up
+struct KeepForHost {
+  __device__ bool operator()(const PlaneOut& o) const { return o.status == ST_DONE || o.status == ST_NOMEM || o.status == ST_WATCHDOG; }
 };
 
 struct Pool {
@@ -1090,6 +1097,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
     o.pad4 = 0;
     o.t_start = t_start;
     o.t_end = (int64_t)wall_clock64();
+    o.w = w;
+    o.pad5 = 0;
     out[w] = o;
   }
 }
@@ -1647,11 +1656,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   unsigned long long* d_cand = cand_raw + n + 64;
   // dispatch order of big rounds: tile minima + sort keys
   const size_t nt1 = (size_t)(n >> TILE1) + 2, nt2 = (size_t)(n >> TILE2) + 2;
-  BS_HIP(ctx, ctx->rg_disp.reserve(sizeof(unsigned long long) * (nt1 + nt2) + sizeof(uint32_t) * 2 * (size_t)wave_cap + 64));
+  BS_HIP(ctx, ctx->rg_disp.reserve(sizeof(unsigned long long) * (nt1 + nt2) + sizeof(uint32_t) * 2 * (size_t)wave_cap + 64 +
+                                    sizeof(PlaneOut) * (size_t)wave_cap));
   unsigned long long* tmin1 = ctx->rg_disp.as<unsigned long long>();
   unsigned long long* tmin2 = tmin1 + nt1;
   uint32_t* dkeys_in = reinterpret_cast<uint32_t*>(tmin2 + nt2);
   uint32_t* dkeys_out = dkeys_in + wave_cap;
+  PlaneOut* d_outc = reinterpret_cast<PlaneOut*>(((uintptr_t)(dkeys_out + wave_cap) + 15) & ~(uintptr_t)15);  // finished attempts of a big round, compacted
   const bool dispatch_order = getenv("BS_NO_DISPATCH_ORDER") == nullptr;  // developer A/B switch
   // positions = the search grid's cell-sorted (Morton) order of THIS cloud when it is cached on the context
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
@@ -1948,8 +1959,24 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       v3_pending = false;
     }
     BS_HIP(ctx, hipMemcpyAsync(h_flags + 10, d_misc + 4, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (ncand)
-      BS_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(PlaneOut) * ncand, hipMemcpyDeviceToHost, st));
+    // A big round's attempts mostly failed at depth 0 (152 k of 158 k in the first round of the 50 M cloud) and the
+    // host never looks at those: only the others travel, in seed order (20 MB each way and a 2 ms walk over
+    // page-locked memory otherwise).  nh = entries on the host, d_outh = the device array they mirror.
+    const bool compact = ncand >= 4096 && !dbg;
+    int nh = ncand;
+    PlaneOut* d_outh = d_out;
+    if (compact) {
+      size_t tb = 0;
+      BS_HIP(ctx, hipcub::DeviceSelect::If(nullptr, tb, d_out, d_outc, d_misc + 12, ncand, KeepForHost(), st));
+      BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
+      BS_HIP(ctx, hipcub::DeviceSelect::If(ctx->cub_tmp.p, tb, d_out, d_outc, d_misc + 12, ncand, KeepForHost(), st));
+      BS_HIP(ctx, hipMemcpyAsync(h_flags + 14, d_misc + 12, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipStreamSynchronize(st));
+      nh = h_flags[14];
+      d_outh = d_outc;
+    }
+    if (nh)
+      BS_HIP(ctx, hipMemcpyAsync(h_out, d_outh, sizeof(PlaneOut) * nh, hipMemcpyDeviceToHost, st));
     if (npend)
       BS_HIP(ctx, hipMemcpyAsync(h_pend, d_pend, sizeof(PlaneOut) * npend, hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
@@ -1963,7 +1990,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // first attempt (by seed index) whose result is not established
     int32_t first_bad = new_min;
     bool nomem_lowest = false;
-    for (int w = 0; w < ncand; w++) {
+    for (int w = 0; w < nh; w++) {
       const PlaneOut& o = h_out[w];
       if (dbg && o.list_n > n + 1)
         fprintf(stderr, "[bs] IMPOSSIBLE list: round %ld w=%d seed=%d status=%d consistent=%d list_n=%ld steps=%ld log=%ld thief=%d\n",
@@ -1972,7 +1999,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): watchdog");
       if (o.status == ST_DONE && (!o.consistent || !o.v3ok))
         first_bad = std::min(first_bad, o.seed);
-      if (w == 0 && o.status == ST_NOMEM)
+      if (o.w == 0 && o.status == ST_NOMEM)
         nomem_lowest = true;
       if (o.status == ST_NOMEM) {
         full_refresh = true;  // its last claims may be neither listed nor reset
@@ -2061,8 +2088,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       pend_room -= (h_pend[w].consistent && h_pend[w].seed >= first_bad) ? 1 : 0;
     {
       int ip = 0, iw = 0;
-      while (ip < npend || iw < ncand) {
-        const bool take_p = (iw >= ncand) || (ip < npend && h_pend[ip].seed < h_out[iw].seed);
+      while (ip < npend || iw < nh) {
+        const bool take_p = (iw >= nh) || (ip < npend && h_pend[ip].seed < h_out[iw].seed);
         PlaneOut& o = take_p ? h_pend[ip] : h_out[iw];
         const int32_t* src = take_p ? pstore : pool.base;
         if (take_p)
@@ -2108,9 +2135,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     if (rc != BS_OK)
       return rc;
     if (dropped) {
-      if (ncand) {
-        BS_HIP(ctx, hipMemcpyAsync(d_out, h_out, sizeof(PlaneOut) * ncand, hipMemcpyHostToDevice, st));
-        plane_apply_kernel<<<ncand, VT, 0, st>>>(d_out, ncand, pool.base, base, ps, dcur, bcur, omega, occ, rec, quads);
+      if (nh) {
+        BS_HIP(ctx, hipMemcpyAsync(d_outh, h_out, sizeof(PlaneOut) * nh, hipMemcpyHostToDevice, st));
+        plane_apply_kernel<<<nh, VT, 0, st>>>(d_outh, nh, pool.base, base, ps, dcur, bcur, omega, occ, rec, quads);
       }
       if (npend) {
         BS_HIP(ctx, hipMemcpyAsync(d_pend, h_pend, sizeof(PlaneOut) * npend, hipMemcpyHostToDevice, st));
