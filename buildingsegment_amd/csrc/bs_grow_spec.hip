@@ -377,7 +377,7 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
     omega[c] = v;
     reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;  // the growth kernel reads the owner from the record
     const uint32_t m0 = hmask[c];
-    const uint8_t want = (m0 != 0 && !ps[c] && v >= prio[c]) ? 1 : 0;
+    const uint8_t want = (m0 != 0 && !(ps[c] & 1) && v >= prio[c]) ? 1 : 0;
     const uint32_t cbit = 1u << (c & 31);
     const uint8_t have = (__hip_atomic_load(occ + (c >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cbit) ? 1 : 0;
     if (want != have) {
@@ -520,19 +520,30 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
   int32_t v = base[c];
   for (int64_t e = roff[c]; e < roff[c + 1]; e++) {
     const int32_t j = radj[e];
-    const bool oj = hmask[j] != 0 && !ps[j] && omega[j] >= prio[j];
+    const bool oj = hmask[j] != 0 && !(ps[j] & 1) && omega[j] >= prio[j];
     if (oj && prio[j] < v)
       v = prio[j];
   }
-  const bool oc = hmask[c] != 0 && !ps[c] && omega[c] >= prio[c];
+  const bool oc = hmask[c] != 0 && !(ps[c] & 1) && omega[c] >= prio[c];
   if (v != omega[c] || (oc ? 1u : 0u) != ((occ[c >> 5] >> (c & 31)) & 1u))
     atomicAdd(nbad, 1);
 }
 
 // ---- plane-attempt candidates -------------------------------------------------
-__global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec, int quads, int K,
+// ps[i]: bit 0 = seed of an inserted (pending or committed) plane, bit 1 = can never seed (static depth-0 mask
+// incomplete; set once by seed_flags_kernel).  The scan reads this ONE byte per point and the owner / original
+// index only of the points that can seed.
+__global__ void seed_flags_kernel(const uint32_t* __restrict__ hmask, int64_t n, int K, uint8_t* __restrict__ ps)
+{
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const uint32_t full = (K - 1 >= 32) ? 0xffffffffu : ((1u << (K - 1)) - 1u);
+  if (i < n)
+    ps[i] = hmask[i] == full ? 0 : 2;
+}
+
+__global__ void cand_flag_kernel(const int4* __restrict__ rec, int quads, int K,
                                  int64_t n, int32_t F, const int32_t* __restrict__ prio, const uint8_t* __restrict__ ps,
-                                 const int32_t* __restrict__ omega, int32_t* min_idx,
+                                 int all_seeds, const int32_t* __restrict__ omega, int32_t* min_idx,
                                  unsigned long long* __restrict__ cand_out, int32_t* cand_count, uint8_t* __restrict__ bcand,
                                  int sub)
 {
@@ -553,21 +564,31 @@ __global__ void cand_flag_kernel(const uint32_t* __restrict__ hmask, const int4*
   }
   __syncthreads();
   unsigned long long gm = sub_mask;
-  const uint32_t full = (K - 1 >= 32) ? 0xffffffffu : ((1u << (K - 1)) - 1u);
   while (gm) {  // (block-uniform trip count: the barrier below is reached by every thread)
     const int t = __ffsll(gm) - 1;
     gm &= gm - 1;
     const int64_t i = ((g0 + t) << 8) + threadIdx.x;
     bool c = false, alive = false;
-    const int32_t pi = i < n ? prio[i] : 0;
-    if (i < n && hmask[i] == full) {
+    const uint8_t f = i < n ? ps[i] : (uint8_t)2;
+    int32_t pi = 0;
+    if (!(f & 2)) {
+      pi = prio[i];
       const int32_t oi = omega[i];
       alive = !(oi < F);  // (a pending plane's seed counts as alive: the plane can still be dropped)
-      if (pi >= F && oi >= pi && !(ps && ps[i])) {  // (ps == nullptr: the audit lists committed seeds too)
+      if (pi >= F && oi >= pi && (all_seeds || !(f & 1))) {  // (all_seeds: the audit lists committed seeds too)
+        // all K-1 neighbours free at the seed's time; four owners per trip, loaded unconditionally (a
+        // short-circuit `c && ...` chains up to K-1 dependent loads one after the other)
         c = true;
         const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
-        for (int u = 1; u < K; u++)
-          c = c && omega[row[u]] >= pi;
+        for (int u = 1; u < K; u += 4) {
+          int32_t ov[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            ov[q] = u + q < K ? omega[row[u + q]] : INF;
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            c = c && ov[q] >= pi;
+        }
       }
     }
     const int any_alive = __syncthreads_or(alive);
@@ -1694,13 +1715,15 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // initial state: no plane; the first owner fixed point is computed by decided states (see
   // decide_pass_kernel), after which nothing is dirty
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
-  BS_HIP(ctx, hipMemsetAsync(ps, 0, n, st));
+  seed_flags_kernel<<<nblk(n, 256), 256, 0, st>>>(hmask, n, K, ps);
   BS_HIP(ctx, hipMemsetAsync(vmark, 0, sizeof(int32_t) * n, st));
   BS_HIP(ctx, hipMemsetAsync(occ, 0, sizeof(uint32_t) * (size_t)((n + 31) / 32 + 2), st));
   int64_t passes = 0;
   // 256-point groups per workgroup of a pass: enough workgroups to fill the chip in the heavy first
   // passes, few enough that an (almost) idle pass costs microseconds
   const int pull_sub = (int)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)nb256 / 4096));
+  // the candidate scan does real work in most groups until the last rounds: fewer groups per workgroup keep it parallel
+  const int cand_sub = std::max(1, pull_sub / 8);
   {
     uint8_t* state = dirty1;   // scratch until the dirty flags are cleared below
     uint8_t* bund = bdirty1;
@@ -1856,7 +1879,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // lowest NEW candidate sees exactly the owners this round starts from unless planes were dropped)
     if (!cand_listed) {
       BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
-      cand_flag_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, nullptr, cand_raw, d_misc + 1, bcand, pull_sub);
+      cand_flag_kernel<<<(int)((nb256 + cand_sub - 1) / cand_sub), 256, 0, st>>>(rec, quads, K, n, F, prio, ps, 0, omega, nullptr, cand_raw, d_misc + 1, bcand, cand_sub);
       BS_HIP(ctx, hipMemcpyAsync(h_flags + 11, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
       ncand_all = h_flags[11];
@@ -1951,7 +1974,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     // same pass, the candidate list of the next round
     const int32_t init2[2] = {0, INF};
     BS_HIP(ctx, hipMemcpyAsync(d_misc + 1, init2, sizeof init2, hipMemcpyHostToDevice, st));
-    cand_flag_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(hmask, rec, quads, K, n, F, prio, ps, omega, d_misc + 2, cand_raw, d_misc + 1, bcand, pull_sub);
+    cand_flag_kernel<<<(int)((nb256 + cand_sub - 1) / cand_sub), 256, 0, st>>>(rec, quads, K, n, F, prio, ps, 0, omega, d_misc + 2, cand_raw, d_misc + 1, bcand, cand_sub);
     // (d_misc[1] = number of candidates listed, d_misc[2] = the lowest one: one copy into the page-locked flags)
     BS_HIP(ctx, hipMemcpyAsync(h_flags + 8, d_misc + 1, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (v3_pending) {  // validate3's verdicts (PlaneOut.v3ok, the refusal counter) are read below
@@ -2211,8 +2234,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, hipMemsetAsync(bcand, 1, nb256, st));
     BS_HIP(ctx, hipMemsetAsync(d_misc + 1, 0, sizeof(int32_t), st));
     BS_HIP(ctx, hipMemsetAsync(d_misc + 8, 0, 2 * sizeof(int32_t), st));
-    cand_flag_kernel<<<(int)((nb256 + pull_sub - 1) / pull_sub), 256, 0, st>>>(hmask, rec, quads, K, n, 0, prio, nullptr, omega, nullptr,
-                                                                              cand_raw, d_misc + 1, bcand, pull_sub);
+    cand_flag_kernel<<<(int)((nb256 + cand_sub - 1) / cand_sub), 256, 0, st>>>(rec, quads, K, n, 0, prio, ps, 1, omega, nullptr,
+                                                                              cand_raw, d_misc + 1, bcand, cand_sub);
     BS_HIP(ctx, hipMemcpyAsync(h_flags + 11, d_misc + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));
     const int na = h_flags[11];
