@@ -50,8 +50,8 @@ PATCHES = [
      "      PROBE(10);\n      // ---- walk the pending calls in order: consume empty ones, stop at the first that accepts ----\n"),
     ("      const int rank = __popcll(am & ((1ull << lane) - 1ull));\n",
      "      PROBE(11);\n      const int rank = __popcll(am & ((1ull << lane) - 1ull));\n"),
-    ('    if (getenv("BS_DEBUG")) {\n      int cnt[6]',
-     '    if (getenv("BS_DEBUG")) {\n      unsigned long long hp[32];\n      hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp));\n'
+    ('    if (dbg) {\n      int cnt[6]',
+     '    if (dbg) {\n      unsigned long long hp[32];\n      hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp));\n'
      '      fprintf(stderr, "[prof] steps=%llu expansions=%llu | src+issue=%llu state=%llu wait=%llu geo+walk=%llu bookA=%llu listS=%llu '
      'push=%llu top=%llu (counter units per step, cumulative over rounds)\\n", hp[8], hp[9], hp[0] / (hp[8] + 1), hp[1] / (hp[8] + 1), '
      'hp[2] / (hp[8] + 1), hp[3] / (hp[8] + 1), hp[4] / (hp[8] + 1), hp[5] / (hp[8] + 1), hp[6] / (hp[8] + 1), hp[7] / (hp[8] + 1));\n'
