@@ -1073,7 +1073,13 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
       status = ST_STOLEN;
   }
   // (a LONG plane -- more than RETRY_MAX_LIST entries thrown away -- gets at most MAX_RETRY_LONG further tries)
-  if (status != ST_STOLEN || attempt >= MAX_RETRY || ln > retry_max_list || (ln > RETRY_MAX_LIST && ++long_tries > MAX_RETRY_LONG))
+  bool seed_taken = false;
+  if (status == ST_STOLEN) {  // my own seed point claimed by an earlier live plane: in the reference this seed never attempts
+    const int t0 = ld_i32(rec_tag(rec, Q, seed_s));
+    seed_taken = t0 < seed && ld_i32(dead + t0) >= 0;
+  }
+  if (status != ST_STOLEN || seed_taken || attempt >= MAX_RETRY || ln > retry_max_list ||
+      (ln > RETRY_MAX_LIST && ++long_tries > MAX_RETRY_LONG))
     break;
   // release this incarnation's claims (points taken over by others keep their new tag) ...
   for (int t = 1 + lane; t < ln; t += 64)
