@@ -64,6 +64,8 @@ namespace bs {
 namespace {
 
 constexpr int32_t INF = 0x7fffffff;
+constexpr int32_t LOWER_BIT = (int32_t)0x80000000;  // in a reverse-list entry: the source's original index is below the target's
+constexpr int32_t POS_MASK = 0x7fffffff;
 constexpr int MAX_WAVES = 1 << 18;  // upper bound of plane attempts grown per round (the 50 M cloud has 158 k candidates in round 1)
 constexpr int MAX_PENDING = 32768;  // finished planes waiting for earlier attempts
 
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
 // proportional to what actually changes, not to n.
 __global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec,
                                                        int quads, int64_t n, unsigned long long* __restrict__ rcur,
-                                                       int32_t* __restrict__ radj)
+                                                       int32_t* __restrict__ radj, const int32_t* __restrict__ prio)
 {
   // same window as static_mask_kernel: count per target in LDS, reserve ONE range per (workgroup, target)
   // with a global atomic on the target's fill cursor (rcur[c] starts at roff[c]), then hand out the slots
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restric
     lcnt[d] = 0;
   __syncthreads();
   const uint32_t m0 = i < n ? hmask[i] : 0u;
+  const int32_t pi = i < n ? prio[i] : 0;  // an entry of R(c) carries LOWER_BIT when its source precedes c in the original order
   const int32_t* row = reinterpret_cast<const int32_t*>(rec + (i < n ? i : 0) * quads + 4);
   for (uint32_t m = m0; m;) {
     const int t = __ffs(m) - 1;
@@ -307,9 +310,9 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restric
     const int32_t c = row[t + 1];
     const int64_t d = (int64_t)c - w0;
     if (d >= 0 && d < RW_WIN)
-      radj[lbase[d] + (unsigned)atomicAdd(&lcnt[d], 1)] = (int32_t)i;
+      radj[lbase[d] + (unsigned)atomicAdd(&lcnt[d], 1)] = (int32_t)i | (pi < prio[c] ? LOWER_BIT : 0);
     else
-      radj[atomicAdd(&rcur[c], 1ull)] = (int32_t)i;
+      radj[atomicAdd(&rcur[c], 1ull)] = (int32_t)i | (pi < prio[c] ? LOWER_BIT : 0);
   }
 }
 
@@ -360,7 +363,7 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
         int32_t pj[4];
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          j[i] = e + i < e1 ? radj[e + i] : -1;
+          j[i] = e + i < e1 ? (radj[e + i] & POS_MASK) : -1;
         // occ is a BITMAP (n / 8 bytes: 6 MB at 50 M points, resident in L2 / Infinity Cache), so the ~14
         // random look-ups per re-evaluated point do not go to HBM
 #pragma unroll
@@ -446,15 +449,23 @@ __global__ void decide_pass_kernel(int64_t n, int sub, const int32_t* __restrict
     const int64_t c = ((g0 + t) << 8) + threadIdx.x;
     bool mine_left = false;
     if (c < n && __hip_atomic_load(st + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      const int32_t pc = prio[c];
       bool lower_occ = false, lower_und = false;
       const int64_t e1 = roff[c + 1];
-      for (int64_t e = roff[c]; e < e1; e++) {
-        const int32_t j = radj[e];
-        if (prio[j] < pc) {
-          const uint8_t sj = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          lower_occ = lower_occ || sj == 1;
-          lower_und = lower_und || sj == 0;
+      // only the sources that precede c matter (LOWER_BIT, decided when the lists were built: no look-up of
+      // their original index); four edges per trip, states loaded for all four before the first is used
+      for (int64_t e = roff[c]; e < e1; e += 4) {
+        int32_t rj[4];
+        uint8_t sj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          rj[q] = e + q < e1 ? radj[e + q] : 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          sj[q] = rj[q] < 0 ? __hip_atomic_load(st + (rj[q] & POS_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          lower_occ = lower_occ || sj[q] == 1;
+          lower_und = lower_und || sj[q] == 0;
         }
       }
       if (lower_occ)
@@ -487,7 +498,7 @@ __global__ void decide_finish_kernel(int64_t n, const int32_t* __restrict__ prio
     int32_t v = INF, vall = INF;
     const int64_t e1 = roff[c + 1];
     for (int64_t e = roff[c]; e < e1; e++) {
-      const int32_t j = radj[e];
+      const int32_t j = radj[e] & POS_MASK;
       const int32_t pj = prio[j];
       vall = pj < vall ? pj : vall;
       if (st[j] == 1)
@@ -519,7 +530,7 @@ __global__ void verify_fixpoint_kernel(int64_t n, const uint32_t* __restrict__ h
     return;
   int32_t v = base[c];
   for (int64_t e = roff[c]; e < roff[c + 1]; e++) {
-    const int32_t j = radj[e];
+    const int32_t j = radj[e] & POS_MASK;
     const bool oj = hmask[j] != 0 && !(ps[j] & 1) && omega[j] >= prio[j];
     if (oj && prio[j] < v)
       v = prio[j];
@@ -1717,7 +1728,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   }
   unsigned long long* rcur = cand_raw;
   BS_HIP(ctx, hipMemcpyAsync(rcur, roff, sizeof(int64_t) * n, hipMemcpyDeviceToDevice, st));
-  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rec, quads, n, rcur, radj);
+  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rec, quads, n, rcur, radj, prio);
   // initial state: no plane; the first owner fixed point is computed by decided states (see
   // decide_pass_kernel), after which nothing is dirty
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);

@@ -6,7 +6,7 @@ python3 - <<PY
 import csv,glob
 f=glob.glob('gpurun_out/r02/ks_tmp/*/*kernel_stats.csv')[0]
 for r in csv.DictReader(open(f)):
-    if 'cand_flag' in r['Name'] or 'pull_pass' in r['Name'] or 'validate2' in r['Name']:
+    if any(k in r["Name"] for k in ("cand_flag", "pull_pass", "decide_", "rev_fill", "static_mask")):
         print("$lib", r['Name'][28:50], int(r['Calls'])//3, 'calls/pass', round(float(r['TotalDurationNs'])/3e6,2), 'ms/pass')
 PY
 done
