@@ -244,6 +244,7 @@ static int knn_normals_dev_impl(bs_ctx* ctx, const int32_t* d_xyz, const int32_t
     return rc;
   T.mark(1);
   ctx->npos_neigh = nullptr;
+  ctx->npos_normals = nullptr;
   rc = launch_knn_normals(ctx, g, q_begin, q_end, *p, d_neigh, d_normals, cert_radius, n_uncertified, d_npos);
   if (rc != BS_OK)
     return rc;
@@ -254,6 +255,7 @@ static int knn_normals_dev_impl(bs_ctx* ctx, const int32_t* d_xyz, const int32_t
   ctx->tm.total_ms = T.ms(0, 2);
   if (d_npos) {  // valid for exactly this neighbour buffer / k (checked by the grower)
     ctx->npos_neigh = d_neigh;
+    ctx->npos_normals = d_normals;
     ctx->npos_k = p->k;
   }
   return BS_OK;
@@ -270,6 +272,10 @@ int bs_knn_normals_dev(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx,
 int bs_region_grow_dev(bs_ctx* ctx, const int32_t* d_xyz, const double* d_normals, const int32_t* d_neigh,
                        int64_t n, const bs_params* p, int32_t* d_plane_idx)
 {
+  if (ctx) {  // the position-ordered copies of the fused pipeline are keyed by pointer, and these buffers' CONTENTS may
+    ctx->npos_neigh = nullptr;  // have changed since: only bs_segment[_dev] itself hands them on to the grower
+    ctx->npos_normals = nullptr;
+  }
   return region_grow_dev_impl(ctx, d_xyz, d_normals, d_neigh, n, p, d_plane_idx, false);
 }
 
@@ -297,7 +303,7 @@ int bs_segment_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const bs_params
   // the fused pipeline also keeps every neighbour's cell-sorted position for the grower (speculative mode)
   int32_t* d_npos = nullptr;
   if (p->rg_mode != 1) {
-    BS_HIP(ctx, ctx->seg_npos.reserve(sizeof(int32_t) * (size_t)n * p->k));
+    BS_HIP(ctx, ctx->seg_npos.reserve(sizeof(int32_t) * ((size_t)n * p->k + 2) + sizeof(double) * 3 * (size_t)n));  // + normals by position
     d_npos = ctx->seg_npos.as<int32_t>();
   }
   rc = knn_normals_dev_impl(ctx, d_xyz, nullptr, n, 0, n, p, d_neigh, d_normals, 0.0, nullptr, d_npos);
@@ -489,6 +495,8 @@ int bs_region_grow(bs_ctx* ctx, const int32_t* xyz, const double* normals, const
   BS_HIP(ctx, hipMemcpyAsync(ctx->d_xyz_h.p, xyz, sizeof(int32_t) * 3 * n, hipMemcpyHostToDevice, st));
   BS_HIP(ctx, hipMemcpyAsync(ctx->d_neigh_h.p, neigh, sizeof(int32_t) * n * p->k, hipMemcpyHostToDevice, st));
   BS_HIP(ctx, hipMemcpyAsync(ctx->d_normals_h.p, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  ctx->npos_neigh = nullptr;  // the staging buffers now hold the caller's data, not what a previous bs_segment searched
+  ctx->npos_normals = nullptr;
   rc = region_grow_dev_impl(ctx, ctx->d_xyz_h.as<int32_t>(), ctx->d_normals_h.as<double>(),
                             ctx->d_neigh_h.as<int32_t>(), n, p, ctx->d_plane_h.as<int32_t>(), true);
   if (rc != BS_OK)

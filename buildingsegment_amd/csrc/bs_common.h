@@ -94,6 +94,14 @@ struct GridDev {
   int64_t n;
 };
 
+// The fused pipeline's position-ordered scratch (bs_ctx::seg_npos): n * K neighbour positions, then the n normals
+// in POSITION order (the grower builds its records by position and would otherwise gather 24 B per point by
+// original index).
+__host__ __device__ inline double* pnorm_of(int32_t* npos, int64_t n, int K)
+{
+  return reinterpret_cast<double*>(npos + (((int64_t)n * K + 1) & ~(int64_t)1));
+}
+
 __host__ __device__ inline uint64_t pack_cell(uint32_t cx, uint32_t cy, uint32_t cz)
 {
   return (uint64_t)cx | ((uint64_t)cy << 21) | ((uint64_t)cz << 42);
@@ -173,6 +181,7 @@ struct bs_ctx {
   // pipeline for the same cloud / k / neigh buffer: the grower takes them instead of translating indices
   bs::DevBuf seg_npos;
   const int32_t* npos_neigh = nullptr;
+  const double* npos_normals = nullptr;
   int npos_k = 0;
 };
 

@@ -645,16 +645,32 @@ __global__ void invert_order_kernel(const int32_t* __restrict__ order, int64_t n
 template <int KC>
 __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ order, const int32_t* __restrict__ pos,
                                      const int32_t* __restrict__ npos, int4* __restrict__ rec, int32_t* __restrict__ prio,
-                                     int4* __restrict__ geo)
+                                     int4* __restrict__ geo, const int4* __restrict__ spts, const double* __restrict__ pnorm)
 {
   const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (s >= a.n)
     return;
   constexpr int Q = RecLayout<KC>::QUADS;
-  const int64_t i = order ? order[s] : s;
+  // fused pipeline: coordinates + original index from the grid's cell-sorted copy, normals from the kNN kernels'
+  // position-ordered copy -- everything streams; otherwise both are gathered by original index
+  int64_t i;
+  int px, py, pz;
+  if (spts) {
+    const int4 p = spts[s];
+    px = p.x;
+    py = p.y;
+    pz = p.z;
+    i = p.w;
+  } else {
+    i = order ? order[s] : s;
+    px = a.xyz[3 * i];
+    py = a.xyz[3 * i + 1];
+    pz = a.xyz[3 * i + 2];
+  }
   int4* r = rec + s * Q;
-  const double nx = a.normals[3 * i], ny = a.normals[3 * i + 1], nz = a.normals[3 * i + 2];
-  r[0] = make_int4(a.xyz[3 * i], a.xyz[3 * i + 1], a.xyz[3 * i + 2], INF);
+  const double* nsrc = pnorm ? pnorm + 3 * s : a.normals + 3 * i;
+  const double nx = nsrc[0], ny = nsrc[1], nz = nsrc[2];
+  r[0] = make_int4(px, py, pz, INF);
   r[1] = make_int4(__double2loint(nx), __double2hiint(nx), __double2loint(ny), __double2hiint(ny));
   r[2] = make_int4(__double2loint(nz), __double2hiint(nz), INF, 0);
   r[3] = make_int4(0, 0, 0, 0);
@@ -1706,15 +1722,19 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
   int32_t* pos = nullptr;
   const int32_t* npos = (order && ctx->npos_neigh == d_neigh && ctx->npos_k == K) ? ctx->seg_npos.as<int32_t>() : nullptr;
+  // (npos only exists for a cloud the fused pipeline just searched WITHOUT global-index indirection: spts[s].w is
+  // the original index then, and the position-ordered normals belong to exactly this normals buffer)
+  const int4* spts_in = npos ? ctx->spts.as<int4>() : nullptr;
+  const double* pnorm_in = (npos && ctx->npos_normals == d_normals) ? pnorm_of(ctx->seg_npos.as<int32_t>(), n, K) : nullptr;
   (void)hipEventRecord(ctx->ev[8], st);
   if (order && !npos) {
     pos = vmark;  // (free until the validation marks are cleared below)
     invert_order_kernel<<<nblk(n, 256), 256, 0, st>>>(order, n, pos);
   }
   if (KC == 16)
-    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio, gs);
+    build_records_kernel<16><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio, gs, spts_in, pnorm_in);
   else
-    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio, gs);
+    build_records_kernel<32><<<nblk(n, 256), 256, 0, st>>>(a, order, pos, npos, rec, prio, gs, spts_in, pnorm_in);
   // static masks + reverse-list counts in one pass, offsets by a 64-bit exclusive scan over n + 1
   // entries (roff[n] = total), then the fill
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));

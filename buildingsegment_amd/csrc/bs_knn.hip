@@ -203,6 +203,12 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
     o[0] = nv.x;
     o[1] = nv.y;
     o[2] = nv.z;
+    if (npos) {  // ... and once more in position order, for the grower's records
+      double* po = pnorm_of(npos, g.n, K) + 3 * s;
+      po[0] = nv.x;
+      po[1] = nv.y;
+      po[2] = nv.z;
+    }
   }
   if (cert_r2 && (kth_final >> 32) >= cert_r2)
     atomicAdd(uncert, 1ull);
@@ -567,6 +573,12 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
       o[0] = nv.x;
       o[1] = nv.y;
       o[2] = nv.z;
+      if (npos) {
+        double* po = pnorm_of(npos, g.n, K) + 3 * (int64_t)s;
+        po[0] = nv.x;
+        po[1] = nv.y;
+        po[2] = nv.z;
+      }
     }
     if (cert_r2 && kd2[K - 1] >= cert_r2)
       atomicAdd(uncert, 1ull);

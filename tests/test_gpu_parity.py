@@ -464,3 +464,23 @@ def test_audit_catches_what_a_disabled_validator_lets_through():
     assert clean_mis == 0
     assert forged_seed >= 0 and forged_refused == 0, "the forgery did not get past the (disabled) validator"
     assert mis >= 1, "the audit did not notice the forged plane"
+
+
+def test_region_grow_after_segment_does_not_reuse_the_fused_scratch(gpu_ctx, oracle):
+    """bs_segment keeps position-ordered copies of its k-lists and normals for the grower, keyed by buffer
+    pointers.  A later bs_region_grow on the same context -- same n, same k, same staging buffers, DIFFERENT
+    neighbour lists and normals -- must not see them."""
+    from buildingsegment_amd import api, synth
+    a = np.ascontiguousarray(synth.plane_cube()[:20000])
+    b = np.ascontiguousarray(synth.urban(60_000, seed=21)[:20000])
+    p = api.default_params(k=15)
+    gpu_ctx.segment(a, p)
+    neigh, normals = oracle.knn_normals(b, k=15)
+    rng = np.random.default_rng(5)
+    nrm = normals + rng.normal(0, 0.05, normals.shape)
+    nrm = np.ascontiguousarray(nrm / np.linalg.norm(nrm, axis=1, keepdims=True))
+    opi, opl = oracle.region_grow(b, nrm, neigh)
+    pi, planes = gpu_ctx.region_grow(b, nrm, neigh, p)
+    assert np.array_equal(pi, opi) and len(planes) == len(opl["id"])
+    if planes:
+        assert np.array_equal(np.concatenate([q.pointIdx for q in planes]), opl["point_idx"])
