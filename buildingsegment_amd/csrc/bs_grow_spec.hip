@@ -198,7 +198,7 @@ constexpr int GW_WIN = 256 + 2 * GW_PAD;
 // of a 128-byte record through L2 -- 1.6 KB of fabric traffic per point.
 __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4* __restrict__ rec, int quads,
                                                           const int4* __restrict__ geo, uint32_t* __restrict__ hmask,
-                                                          int32_t* __restrict__ rcnt)
+                                                          int32_t* __restrict__ rcnt, uint32_t* __restrict__ lmask)
 {
   __shared__ int lcnt[RW_WIN];
   __shared__ int4 lgeo[GW_WIN * 3];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
                  cnz = __hiloint2double(s2.y, s2.x);
     const int ccx = s0.x, ccy = s0.y, ccz = s0.z;
     const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
-    uint32_t m = 0;
+    uint32_t m = 0, lm = 0;  // lm: bit t-1 set when this point precedes neighbour t in the original order
     for (int t = 1; t < a.K; t++) {
       const int32_t c = row[t];
       const int64_t gd = (int64_t)c - g0;
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
                         cnz * __hiloint2double(q2.y, q2.x);
       if (dist <= a.th && dt >= a.cos_th) {
         m |= 1u << (t - 1);
+        lm |= (s0.w < q0.w ? 1u : 0u) << (t - 1);
         const int64_t d = (int64_t)c - w0;  // |R(c)|: the reverse lists are counted in the same pass
         if (d >= 0 && d < RW_WIN)
           atomicAdd(&lcnt[d], 1);
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
       }
     }
     hmask[i] = m;
+    lmask[i] = lm;
   }
   __syncthreads();
   for (int d = threadIdx.x; d < RW_WIN; d += 256) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
 // proportional to what actually changes, not to n.
 __global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec,
                                                        int quads, int64_t n, unsigned long long* __restrict__ rcur,
-                                                       int32_t* __restrict__ radj, const int32_t* __restrict__ prio)
+                                                       int32_t* __restrict__ radj, const uint32_t* __restrict__ lmask)
 {
   // same window as static_mask_kernel: count per target in LDS, reserve ONE range per (workgroup, target)
   // with a global atomic on the target's fill cursor (rcur[c] starts at roff[c]), then hand out the slots
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restric
     lcnt[d] = 0;
   __syncthreads();
   const uint32_t m0 = i < n ? hmask[i] : 0u;
-  const int32_t pi = i < n ? prio[i] : 0;  // an entry of R(c) carries LOWER_BIT when its source precedes c in the original order
+  const uint32_t lm0 = i < n ? lmask[i] : 0u;  // an entry of R(c) carries LOWER_BIT when its source precedes c in the original order
   const int32_t* row = reinterpret_cast<const int32_t*>(rec + (i < n ? i : 0) * quads + 4);
   for (uint32_t m = m0; m;) {
     const int t = __ffs(m) - 1;
@@ -310,9 +312,9 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restric
     const int32_t c = row[t + 1];
     const int64_t d = (int64_t)c - w0;
     if (d >= 0 && d < RW_WIN)
-      radj[lbase[d] + (unsigned)atomicAdd(&lcnt[d], 1)] = (int32_t)i | (pi < prio[c] ? LOWER_BIT : 0);
+      radj[lbase[d] + (unsigned)atomicAdd(&lcnt[d], 1)] = (int32_t)i | (((lm0 >> t) & 1u) ? LOWER_BIT : 0);
     else
-      radj[atomicAdd(&rcur[c], 1ull)] = (int32_t)i | (pi < prio[c] ? LOWER_BIT : 0);
+      radj[atomicAdd(&rcur[c], 1ull)] = (int32_t)i | (((lm0 >> t) & 1u) ? LOWER_BIT : 0);
   }
 }
 
@@ -674,7 +676,9 @@ __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ ord
   r[1] = make_int4(__double2loint(nx), __double2hiint(nx), __double2loint(ny), __double2hiint(ny));
   r[2] = make_int4(__double2loint(nz), __double2hiint(nz), INF, 0);
   r[3] = make_int4(0, 0, 0, 0);
-  geo[3 * s] = r[0];  // compact geometry (48 B per position) for the LDS tiles of static_mask_kernel
+  // compact geometry (48 B per position) for the LDS tiles of static_mask_kernel; its spare word carries the
+  // original index, so that the kernel can also tell which neighbours a point precedes
+  geo[3 * s] = make_int4(px, py, pz, (int32_t)i);
   geo[3 * s + 1] = r[1];
   geo[3 * s + 2] = r[2];
   prio[s] = (int32_t)i;
@@ -1738,7 +1742,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // static masks + reverse-list counts in one pass, offsets by a 64-bit exclusive scan over n + 1
   // entries (roff[n] = total), then the fill
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));
-  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, rec, quads, gs, hmask, rpos);
+  uint32_t* lmask = reinterpret_cast<uint32_t*>(vmark);  // (free until the validation marks are cleared after the fill)
+  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, rec, quads, gs, hmask, rpos, lmask);
   {
     hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*> in(rpos, ToI64());
     size_t tb = 0;
@@ -1748,7 +1753,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   }
   unsigned long long* rcur = cand_raw;
   BS_HIP(ctx, hipMemcpyAsync(rcur, roff, sizeof(int64_t) * n, hipMemcpyDeviceToDevice, st));
-  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rec, quads, n, rcur, radj, prio);
+  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rec, quads, n, rcur, radj, lmask);
   // initial state: no plane; the first owner fixed point is computed by decided states (see
   // decide_pass_kernel), after which nothing is dirty
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
