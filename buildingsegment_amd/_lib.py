@@ -21,7 +21,9 @@ EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "b
            "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_knn_normals_halo", "bs_region_grow", "bs_segment",
            "bs_planes_free", "bs_plane_colors", "bs_knn_normals_dev", "bs_region_grow_dev",
            "bs_segment_dev", "bs_planes_fetch", "bs_shift_to_origin_dev", "bs_plane_colors_dev",
-           "bs_selftest_center_div", "bs_selftest_forge_next", "bs_set_audit", "bs_ingest_dev", "bs_grid_dims", "bs_grid_picture", "bs_grid_picture_dev"]
+           "bs_selftest_center_div", "bs_selftest_forge_next", "bs_set_audit", "bs_ingest_dev", "bs_grid_dims", "bs_grid_picture", "bs_grid_picture_dev",
+           "bs_cc_hook_dev", "bs_owner_fetch_dev", "bs_labels_from_owner_dev", "bs_remap_rows_dev",
+           "bs_plane_seeds_dev", "bs_stream_sync"]
 
 
 class Params(C.Structure):
@@ -97,5 +99,11 @@ def load():
     L.bs_grid_dims.argtypes = [ip, C.c_int32, ip, ip]
     L.bs_grid_picture.argtypes = [vp, ip, C.c_int64, ip, C.c_int32, C.c_int32, dp, dp]
     L.bs_grid_picture_dev.argtypes = [vp, ip, C.c_int64, ip, C.c_int32, C.c_int32, dp, dp]
+    L.bs_cc_hook_dev.argtypes = [vp, ip, ip, C.c_int64, C.c_int32, ip, C.c_int64, lp]
+    L.bs_owner_fetch_dev.argtypes = [vp, ip]
+    L.bs_plane_seeds_dev.argtypes = [vp, ip, C.c_int64, C.POINTER(C.c_int32)]
+    L.bs_stream_sync.argtypes = [vp]
+    L.bs_labels_from_owner_dev.argtypes = [vp, ip, C.c_int64, ip, C.c_int32, ip]
+    L.bs_remap_rows_dev.argtypes = [vp, ip, C.c_int64, C.c_int32, ip, C.c_int64, ip, C.POINTER(C.c_int32)]
     _LIB = L
     return L

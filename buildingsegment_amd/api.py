@@ -225,6 +225,35 @@ class Context:
         timings()['audit_mismatches'] must be 0."""
         self._check(self._L.bs_set_audit(self._h, 1 if on else 0))
 
+    # ---- building blocks of the component-sharded stage 3 (device pointers) ----
+    def cc_hook_dev(self, d_rows, d_gidx, m, k, d_parent, n_total) -> int:
+        """One hooking step of the distributed union-find (bs_cc_hook_dev); returns the unions performed."""
+        h = C.c_int64(0)
+        self._check(self._L.bs_cc_hook_dev(self._h, d_rows or None, d_gidx or None, m, k, d_parent, n_total, C.byref(h)))
+        return h.value
+
+    def owner_fetch_dev(self, d_owner):
+        """owner[p] of the last speculative grow on this context, in the caller's index order (-1: unlabelled)."""
+        self._check(self._L.bs_owner_fetch_dev(self._h, d_owner))
+
+    def plane_seeds_dev(self, d_seeds, cap) -> int:
+        """Seeds of the committed planes of the last speculative grow (ascending) into d_seeds; returns their number."""
+        npl = C.c_int32(0)
+        self._check(self._L.bs_plane_seeds_dev(self._h, d_seeds or None, cap, C.byref(npl)))
+        return npl.value
+
+    def sync(self):
+        self._check(self._L.bs_stream_sync(self._h))
+
+    def labels_from_owner_dev(self, d_owner, n, d_seeds, n_seeds, d_plane_idx):
+        self._check(self._L.bs_labels_from_owner_dev(self._h, d_owner or None, n, d_seeds or None, n_seeds, d_plane_idx or None))
+
+    def remap_rows_dev(self, d_rows, n_rows, k, d_sorted_gidx, n, d_out) -> int:
+        miss = C.c_int32(0)
+        self._check(self._L.bs_remap_rows_dev(self._h, d_rows or None, n_rows, k, d_sorted_gidx or None, n, d_out or None,
+                                              C.byref(miss)))
+        return miss.value
+
     def planes_fetch(self):
         P = Planes()
         self._check(self._L.bs_planes_fetch(self._h, C.byref(P)))

@@ -168,6 +168,12 @@ struct bs_ctx {
   bs::HostBuf rg_hout;  // PlaneOut[wave_cap + MAX_PENDING] + a few scalars, page-locked
   int64_t rg_n = 0;
   bool rg_valid = false;
+  // final owner structure of the last speculative grow (inside rg_aux): owner by POSITION and the original index
+  // of every position -- what bs_owner_fetch_dev maps back to the caller's order
+  const int32_t* rg_omega = nullptr;
+  const int32_t* rg_prio = nullptr;
+  const int32_t* rg_seeds = nullptr;  // committed seeds (original indices, ascending = commit order), device
+  int32_t rg_nplanes = 0;
   int forge_mode = 0;  // bs_selftest_forge_next
   int audit = 0;       // bs_set_audit
   hipStream_t side = nullptr;  // second stream of the grower (validate3 beside the owner passes)
@@ -199,6 +205,7 @@ int fail(bs_ctx* ctx, int status, const char* what, hipError_t e = hipSuccess);
 // grid.hip
 int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t n, double radius,
                int k, int cell_hint, GridDev* out);
+int build_spatial_order(bs_ctx* ctx, const int32_t* d_xyz, int64_t n);
 // knn.hip
 int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q_end,
                        const bs_params& p, int32_t* d_neigh, double* d_normals, double cert_radius,

@@ -317,4 +317,53 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
   return BS_OK;
 }
 
+// Spatial (Morton) order of a cloud WITHOUT a search grid: what the region grower needs when it is handed
+// foreign buffers (bs_region_grow[_dev], the component-sharded stage 3) -- its records, masks, reverse lists and
+// owner passes address points by their position in a spatially coherent order (bs_grow_spec.hip, "Index
+// spaces"); with the identity order every neighbour is a random HBM access.  One bounding-box pass, one key
+// pass, one radix sort over exactly the key bits in use.  Any int32 coordinates are admissible (no exact-moment
+// domain here: only an order is produced).  Result: ctx->vals_out = original index of every position.
+int build_spatial_order(bs_ctx* ctx, const int32_t* d_xyz, int64_t n)
+{
+  hipStream_t st = ctx->stream;
+  if (n <= 0 || n >= (int64_t)INT_MAX - 64)
+    return fail(ctx, BS_ERR_INVALID, "point count out of range");
+  BS_HIP(ctx, ctx->misc.reserve(256));
+  BS_HIP(ctx, ctx->keys_in.reserve(sizeof(uint64_t) * n));
+  BS_HIP(ctx, ctx->keys_out.reserve(sizeof(uint64_t) * n));
+  BS_HIP(ctx, ctx->vals_in.reserve(sizeof(int32_t) * n));
+  BS_HIP(ctx, ctx->vals_out.reserve(sizeof(int32_t) * n));
+  int32_t init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
+  int32_t* d_mnmx = ctx->misc.as<int32_t>();
+  BS_HIP(ctx, hipMemcpyAsync(d_mnmx, init, sizeof init, hipMemcpyHostToDevice, st));
+  bbox_kernel<<<std::min(grid_blocks(n, 256), 512), 256, 0, st>>>(d_xyz, n, d_mnmx);
+  int32_t bb[6];
+  BS_HIP(ctx, hipMemcpyAsync(bb, d_mnmx, sizeof bb, hipMemcpyDeviceToHost, st));
+  BS_HIP(ctx, hipStreamSynchronize(st));
+  int64_t ext = 1;
+  for (int a = 0; a < 3; a++)
+    ext = std::max<int64_t>(ext, (int64_t)bb[3 + a] - bb[a] + 1);
+  // cells of >= 128 mm (a few points each at the densities of SURVEY 8(d)): fewer key bits = fewer radix passes
+  int64_t cell = 128;
+  while (ext / cell + 1 >= (1 << 21))
+    cell *= 2;
+  int bits = 1;
+  while (((int64_t)1 << bits) < ext / cell + 1)
+    bits++;
+  uint64_t* kin = ctx->keys_in.as<uint64_t>();
+  uint64_t* kout = ctx->keys_out.as<uint64_t>();
+  int32_t* vin = ctx->vals_in.as<int32_t>();
+  int32_t* vout = ctx->vals_out.as<int32_t>();
+  cellkey_kernel<<<grid_blocks(n, 256), 256, 0, st>>>(d_xyz, n, bb[0], bb[1], bb[2], (int)cell, 1, kin, vin);
+  const int end_bit = std::min(63, 3 * bits);
+  size_t tb = 0;
+  BS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, kout, vin, vout, (int)n, 0, end_bit, st));
+  BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
+  BS_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tb, kin, kout, vin, vout, (int)n, 0, end_bit, st));
+  BS_HIP(ctx, hipGetLastError());
+  ctx->order_n = n;
+  ctx->order_xyz = d_xyz;
+  return BS_OK;
+}
+
 }  // namespace bs

@@ -231,6 +231,10 @@ int launch_region_grow_seq(bs_ctx* ctx, const int32_t* d_xyz, const double* d_no
 {
   hipStream_t st = ctx->stream;
   ctx->rg_valid = false;
+  ctx->rg_omega = nullptr;  // (the single-wave grower keeps no owner array: bs_owner_fetch_dev refuses)
+  ctx->rg_prio = nullptr;
+  ctx->rg_seeds = nullptr;
+  ctx->rg_nplanes = 0;
   const int64_t list_cap = 2 * n + 64;
   const int64_t stack_cap = n + 64;
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;

@@ -1620,6 +1620,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
 {
   hipStream_t st = ctx->stream;
   ctx->rg_valid = false;
+  ctx->rg_omega = nullptr;
+  ctx->rg_prio = nullptr;
+  ctx->rg_seeds = nullptr;
+  ctx->rg_nplanes = 0;
   const int K = p.k;
   const int64_t list_cap = 2 * n + 64;
   const int64_t planes_cap = n / std::max(1, p.th_point_count) + 64;
@@ -1726,11 +1730,25 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int32_t* order = (ctx->order_n == n && ctx->order_xyz == d_xyz) ? ctx->vals_out.as<int32_t>() : nullptr;
   int32_t* pos = nullptr;
   const int32_t* npos = (order && ctx->npos_neigh == d_neigh && ctx->npos_k == K) ? ctx->seg_npos.as<int32_t>() : nullptr;
+  (void)hipEventRecord(ctx->ev[8], st);
+  if (!npos) {
+    // Foreign input (bs_region_grow[_dev], the component-sharded stage 3): no search grid of THIS cloud's current
+    // contents is at hand (a cached order is keyed by pointer only).  The grower builds the Morton order itself --
+    // bounding box, keys, one radix sort -- instead of falling back to the identity, where every neighbour of every
+    // pass is a random HBM access (setup 134 ms instead of 31 at 50 M, HBM-latency steps).
+    static const bool identity = getenv("BS_FOREIGN_ORDER_IDENTITY") != nullptr;  // developer A/B switch
+    order = nullptr;
+    if (!identity) {
+      const int orc = build_spatial_order(ctx, d_xyz, n);
+      if (orc != BS_OK)
+        return orc;
+      order = ctx->vals_out.as<int32_t>();
+    }
+  }
   // (npos only exists for a cloud the fused pipeline just searched WITHOUT global-index indirection: spts[s].w is
   // the original index then, and the position-ordered normals belong to exactly this normals buffer)
   const int4* spts_in = npos ? ctx->spts.as<int4>() : nullptr;
   const double* pnorm_in = (npos && ctx->npos_normals == d_normals) ? pnorm_of(ctx->seg_npos.as<int32_t>(), n, K) : nullptr;
-  (void)hipEventRecord(ctx->ev[8], st);
   if (order && !npos) {
     pos = vmark;  // (free until the validation marks are cleared below)
     invert_order_kernel<<<nblk(n, 256), 256, 0, st>>>(order, n, pos);
@@ -2253,6 +2271,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   BS_HIP(ctx, hipGetLastError());
   ctx->rg_n = n;
   ctx->rg_valid = true;
+  ctx->rg_omega = owner_final;
+  ctx->rg_prio = prio;
+  ctx->rg_seeds = d_seeds;
+  ctx->rg_nplanes = np;
   ctx->tm.largest_plane = largest;
   ctx->tm.n_seed_attempts = attempts;
   ctx->tm.rg_rounds = rounds;

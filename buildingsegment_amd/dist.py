@@ -2,9 +2,9 @@
 GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
 CPU tests and in one-GPU rehearsals).
 
-What shards and what does not (reference loops:
-/root/reference/tmc3/my_function.h:63 normals, :71-78 kNN; the ordered scan
-that stays serial: /root/reference/tmc3/my_function.cpp:184-217):
+All three stages shard (reference loops:
+/root/reference/tmc3/my_function.h:63 normals, :71-78 kNN,
+/root/reference/tmc3/my_function.cpp:184-217 the ordered seed scan):
 
   * stages 1-2 (kNN + normals) are independent per query after ONE exchange step.
     Every rank starts from an arbitrary 1/N of the cloud (+ global indices):
@@ -17,20 +17,47 @@ that stays serial: /root/reference/tmc3/my_function.cpp:184-217):
       3. slab kNN + normals (bs_knn_normals_dev with d_gidx: ties by GLOBAL index,
          global indices out).  A k-list is exact iff its k-th distance is < h;
          ranks agree (all-reduce MAX) to retry with a doubled halo otherwise.
-  * stage 3 (region growing) is order dependent and sequential per plane: it is
-    NOT sharded -- "replicas only".  xyz / neigh / normals are sent to rank 0
-    (one all-to-all whose only receiver is rank 0), rank 0 grows, labels are
-    broadcast.
+  * stage 3 (region growing) is a scan over ALL seeds in index order, but information
+    only travels along kNN edges (Broad tests neigh[Idx][1..K-1], my_function.cpp:224-233;
+    a failed seed labels part of its own row, :238-239): connected components of the kNN
+    graph never interact, and the only shared state is cur_planeId, which advances once per
+    committed plane (:199-202):
+        planeIdx[p] = 1 + #(committed seeds < owner[p]),  owner[p] = the attempt that left p labelled.
+    So it shards EXACTLY by components:
+      4. components: union-find on a parent array over global ids -- every rank hooks its
+         slab's rows (bs_cc_hook_dev), the parent arrays are all-reduced with MIN (the "label
+         union-find" all-reduce over xGMI), repeated until no rank hooked anything;
+      5. components are dealt to the ranks (largest first, preferring the rank that already
+         holds most of the component, bounded imbalance) and their points (xyz, gidx, normal,
+         k-list) move there in ONE all-to-all per array;
+      6. every rank sorts what it received by global index (local order = global order
+         restricted to it, so "the earlier seed wins" means the same thing), renumbers the
+         k-lists (bs_remap_rows_dev) and grows its components with the single-GPU scheduler
+         (bs_region_grow_dev) -- bit-identical to what the sequential scan does inside them;
+      7. the committed seeds are all-gathered and sorted, labels follow from the owners
+         (bs_owner_fetch_dev, bs_labels_from_owner_dev), plane ids from the seeds' ranks;
+         one all-reduce(MAX) assembles the label array on every rank.
+    A cloud that is ONE component (a single facade) lands on one rank: exactness never
+    depends on the split, only the speed-up does.  The bound on the speed-up is the longest
+    chain of dependent planes inside one component.
 
 Every buffer stays on the compute device: with nccl the collectives run on the
 device tensors themselves (no .cpu(), no numpy); with gloo the SAME code stages
 each collective through host memory inside `_coll` (gloo has no device
 transport) -- that is the only difference between the two backends.
 
+A failure on one rank (a BsError of its compute backend, an inconsistent partition) is
+agreed on by all ranks BEFORE the next collective (`_agree`): every rank raises, nobody is left
+waiting in a collective.
+
 The compute backend is injected so that the orchestration is covered on CPU:
     knn_normals(xyz_loc [n,3] i32, gidx_loc [n] i32, n_query, params, cert_radius)
         -> (neigh [n_query,k] i32 GLOBAL indices, normals [n_query,3] f64, n_uncertified)
-    region_grow(xyz [n,3], normals [n,3], neigh [n,k], params) -> (labels [n] i32, planes | None)
+    cc_hook(rows [m,k] i32 global ids, gidx [m] i32, parent [n_total] i32 in/out) -> unions performed
+    remap_rows(rows [m,k] i32 global ids, sorted_gidx [m] i32) -> (rows as local indices, n_missing)
+    region_grow(xyz [n,3], normals [n,3], neigh [n,k], params)
+        -> (labels [n] i32, owner [n] i32, seeds [np] i32 ascending, planes_fn() -> planes | None)
+    labels_from_owner(owner [n] i32 GLOBAL seed index or -1, seeds [np] i32 ascending) -> labels [n] i32
 `DevBackend` wraps an api.Context (HIP, device pointers); tests/test_dist_gloo.py
 injects a CPU backend of its own.
 """
@@ -89,8 +116,12 @@ def partition_morton(xyz: np.ndarray, world: int, rank: int):
 
 
 # --------------------------------------------------------------------------
-# collectives on device tensors
+# collectives on device tensors (ONE code path for both backends: gloo runs the
+# same calls on the host copy `_coll` makes)
 # --------------------------------------------------------------------------
+
+FORCE_COLLECTIVES = False  # tests: issue the collectives even at world size 1 (the nccl branch on a one-GPU box)
+
 
 def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -100,8 +131,14 @@ def _rank(group=None) -> int:
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
+def _live(group=None) -> bool:
+    """Do the collectives have to be issued?  (world > 1, or forced at world 1 with an initialised group.)"""
+    w = _world(group)
+    return w > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def _host_staged(group=None) -> bool:
-    return _world(group) > 1 and dist.get_backend(group) != "nccl"
+    return _live(group) and dist.get_backend(group) != "nccl"
 
 
 def _coll(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -110,7 +147,7 @@ def _coll(t: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def all_reduce_(t: torch.Tensor, op, group=None) -> torch.Tensor:
-    if _world(group) == 1:
+    if not _live(group):
         return t
     c = _coll(t, group)
     dist.all_reduce(c, op=op, group=group)
@@ -121,21 +158,35 @@ def all_reduce_(t: torch.Tensor, op, group=None) -> torch.Tensor:
 
 def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather of equally shaped tensors, concatenated along dim 0."""
-    w = _world(group)
-    if w == 1:
+    if not _live(group):
         return t
+    w = _world(group)
     c = _coll(t.contiguous(), group)
     out = torch.empty((w * c.shape[0],) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device)
-    dist.all_gather_into_tensor(out, c, group=group) if c.is_cuda else dist.all_gather(list(out.chunk(w)), c, group=group)
+    dist.all_gather_into_tensor(out, c, group=group)
     return out.to(t.device)
+
+
+def all_gather_var(t: torch.Tensor, group=None):
+    """All-gather of tensors whose dim 0 differs per rank: counts first, then ONE padded all-gather.
+    Returns (concatenation in rank order, counts list)."""
+    if not _live(group):
+        return t, [int(t.shape[0])]
+    w = _world(group)
+    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    cnts = [int(v) for v in all_gather_rows(cnt, group).tolist()]
+    cap = max(max(cnts), 1)
+    pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    allp = all_gather_rows(pad, group).reshape((w, cap) + tuple(t.shape[1:]))
+    return torch.cat([allp[r, :cnts[r]] for r in range(w)]), cnts
 
 
 def all_to_all_rows(rows: torch.Tensor, send_counts: torch.Tensor, group=None):
     """rows [m, c] sorted by destination rank, send_counts [world] (int64, on rows.device).
     Returns (received rows, recv_counts list).  Counts travel first (tiny all-to-all), then ONE
     payload all-to-all with split sizes -- only what a peer needs crosses xGMI."""
-    w = _world(group)
-    if w == 1:
+    if not _live(group):
         return rows, [int(rows.shape[0])]
     sc = _coll(send_counts.to(torch.int64), group)
     rc = torch.empty_like(sc)
@@ -153,13 +204,29 @@ def _sync(t: torch.Tensor):
         torch.cuda.synchronize(t.device)
 
 
+class ShardError(RuntimeError):
+    """Raised on EVERY rank when any rank failed in a phase of the sharded pass."""
+
+
+def _agree(err, what: str, dev, group=None):
+    """Every rank reports whether its last phase failed; if any did, all raise -- before the next collective,
+    so that a failure on one rank can never leave the others waiting in it."""
+    flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=dev)
+    all_reduce_(flag, dist.ReduceOp.MAX, group)
+    if int(flag.item()):
+        if err is not None:
+            raise ShardError(f"rank {_rank(group)} failed in {what}: {err}") from err
+        raise ShardError(f"another rank failed in {what}")
+
+
 # --------------------------------------------------------------------------
 # compute backend over the C ABI (device pointers)
 # --------------------------------------------------------------------------
 
 class DevBackend:
-    """api.Context as the slab compute backend: tensors live on the context's GPU and go
-    through bs_knn_normals_dev / bs_region_grow_dev as raw device pointers."""
+    """api.Context as the compute backend: tensors live on the context's GPU and go through the C ABI
+    (bs_knn_normals_dev, bs_cc_hook_dev, bs_remap_rows_dev, bs_region_grow_dev, bs_owner_fetch_dev,
+    bs_labels_from_owner_dev) as raw device pointers."""
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -173,12 +240,37 @@ class DevBackend:
                                        q_begin=0, q_end=n_query, d_gidx=gidx_loc.data_ptr(), cert_radius=cert_radius)
         return neigh, normals, int(unc)
 
+    def cc_hook(self, rows, gidx, parent):
+        _sync(parent)
+        return self.ctx.cc_hook_dev(rows.data_ptr(), gidx.data_ptr(), int(rows.shape[0]), int(rows.shape[1]),
+                                    parent.data_ptr(), int(parent.shape[0]))
+
+    def remap_rows(self, rows, sorted_gidx):
+        out = torch.empty_like(rows)
+        _sync(rows)
+        miss = self.ctx.remap_rows_dev(rows.data_ptr(), int(rows.shape[0]), int(rows.shape[1]), sorted_gidx.data_ptr(),
+                                       int(sorted_gidx.shape[0]), out.data_ptr())
+        return out, miss
+
     def region_grow(self, xyz, normals, neigh, params):
         n = int(xyz.shape[0])
         labels = torch.empty((n,), dtype=torch.int32, device=xyz.device)
+        owner = torch.empty((n,), dtype=torch.int32, device=xyz.device)
         _sync(xyz)
         self.ctx.region_grow_dev(xyz.data_ptr(), normals.data_ptr(), neigh.data_ptr(), n, labels.data_ptr(), params)
-        return labels, self.ctx.planes_fetch()
+        self.ctx.owner_fetch_dev(owner.data_ptr())
+        seeds = torch.empty((self.ctx.plane_seeds_dev(0, 0),), dtype=torch.int32, device=xyz.device)
+        self.ctx.plane_seeds_dev(seeds.data_ptr(), int(seeds.shape[0]))
+        self.ctx.sync()
+        return labels, owner, seeds, self.ctx.planes_fetch
+
+    def labels_from_owner(self, owner, seeds):
+        labels = torch.empty_like(owner)
+        _sync(owner)
+        self.ctx.labels_from_owner_dev(owner.data_ptr(), int(owner.shape[0]), seeds.data_ptr(), int(seeds.shape[0]),
+                                       labels.data_ptr())
+        self.ctx.sync()
+        return labels
 
 
 # --------------------------------------------------------------------------
@@ -195,7 +287,7 @@ def _partition(rows: torch.Tensor, world: int, group=None, samples: int = 1024):
     all_reduce_(mx, dist.ReduceOp.MAX, group)
     ext = int((mx - mn).max().item())
     shift = max(ext.bit_length() - 21, 0)
-    if world == 1:
+    if not _live(group):
         return rows, mn
     keys = morton_keys_t(rows[:, :3], mn, shift)
     skeys, order = torch.sort(keys)
@@ -219,7 +311,7 @@ def _partition(rows: torch.Tensor, world: int, group=None, samples: int = 1024):
 def _halo(own: torch.Tensor, origin: torch.Tensor, h: float, world: int, rank: int, group=None):
     """own [m,4].  Returns the halo rows [*,4] this rank receives for halo width h."""
     dev = own.device
-    if world == 1:
+    if not _live(group):
         return own[:0]
     v = max(int(math.ceil(h)), 500)
     vox = torch.div(own[:, :3].to(torch.int64) - origin[None, :], v, rounding_mode="floor") + 1  # +1: room for the -1 offsets
@@ -246,15 +338,183 @@ def _halo(own: torch.Tensor, origin: torch.Tensor, h: float, world: int, rank: i
     return got  # a point has one owner and is sent to a peer at most once: no duplicates
 
 
+def _components(backend, neigh: torch.Tensor, gidx_own: torch.Tensor, n_total: int, group=None, max_iters: int = 64):
+    """Connected components of the kNN graph whose rows are spread over the ranks.  Returns
+    (root [m] int32 = smallest global index of each own point's component, iterations)."""
+    dev = neigh.device
+    parent = torch.arange(n_total, dtype=torch.int32, device=dev)
+    it = 0
+    while True:
+        it += 1
+        err, hooks = None, 0
+        try:
+            hooks = backend.cc_hook(neigh, gidx_own, parent) if neigh.shape[0] else 0
+        except Exception as e:  # noqa: BLE001 -- agreed on by all ranks below
+            err = e
+        _agree(err, "connected components", dev, group)
+        if not _live(group):
+            break
+        all_reduce_(parent, dist.ReduceOp.MIN, group)  # the union-find all-reduce over xGMI
+        flag = torch.tensor([hooks], dtype=torch.int64, device=dev)
+        all_reduce_(flag, dist.ReduceOp.SUM, group)
+        if int(flag.item()) == 0:
+            break  # no rank had an edge whose ends disagreed: parent (identical everywhere) is final
+        if it >= max_iters:
+            _agree(RuntimeError("union-find did not settle"), "connected components", dev, group)
+    return parent[gidx_own.to(torch.int64)], it
+
+
+def assign_components(roots: np.ndarray, counts: np.ndarray, ranks: np.ndarray, world: int, slack: float = 0.10,
+                      exact_top: int = 8192):
+    """Deal components to ranks.  Input: one (root, count, rank) triple per (component, rank holding part of it).
+    Largest first; a component goes to the rank that already holds most of it unless that would put the rank
+    more than `slack` above the mean load and above what the least loaded rank would reach.  Everything beyond the
+    `exact_top` largest stays where most of it is (no traffic; those are small).  Deterministic: every rank
+    computes the same answer from the same gathered triples.  Returns (unique roots ascending, dest rank of each)."""
+    uniq, inv = np.unique(roots, return_inverse=True)
+    per = np.zeros((len(uniq), world), np.int64)
+    np.add.at(per, (inv, ranks), counts)
+    size = per.sum(1)
+    home = per.argmax(1)
+    dest = home.astype(np.int64).copy()
+    order = np.lexsort((uniq, -size))
+    top = order[:exact_top]
+    load = np.zeros(world, np.int64)
+    rest = order[exact_top:]
+    if len(rest):
+        np.add.at(load, home[rest], size[rest])
+    cap = (1.0 + slack) * float(size.sum()) / world
+    for c in top:
+        h = int(home[c])
+        least = int(load.argmin())
+        d = h if load[h] + size[c] <= max(cap, load[least] + size[c]) else least
+        dest[c] = d
+        load[d] += size[c]
+    return uniq, dest
+
+
+def _grow_components(backend, own, neigh, normals, n_total, params, group, st, tick, t0, want_planes):
+    """Stage 3, sharded by connected components (steps 4-7 of the module docstring)."""
+    world, rank = _world(group), _rank(group)
+    dev = own.device
+    k = params.k
+    info = {}
+    if _live(group):
+        root, cc_iters = _components(backend, neigh, own[:, 3].contiguous(), n_total, group)
+        t0 = tick("components_ms", t0)
+        # (root, points of it here) of every rank -> the same deal on every rank
+        uroot, ucnt = torch.unique(root, return_counts=True)
+        tri = torch.stack([uroot.to(torch.int64), ucnt.to(torch.int64)], 1)
+        alltri, cnts = all_gather_var(tri, group)
+        alltri = alltri.cpu().numpy()
+        ranks = np.repeat(np.arange(world), cnts)
+        uniq, dest = assign_components(alltri[:, 0], alltri[:, 1], ranks, world)
+        uniq_t = torch.from_numpy(uniq).to(dev)
+        dest_t = torch.from_numpy(dest).to(dev)
+        dpt = dest_t[torch.searchsorted(uniq_t, root.to(torch.int64))]
+        order = torch.sort(dpt, stable=True).indices
+        counts = torch.bincount(dpt, minlength=world)
+        g_own, _ = all_to_all_rows(own[order], counts, group)
+        g_ng, _ = all_to_all_rows(neigh[order], counts, group)
+        g_nr, _ = all_to_all_rows(normals[order], counts, group)
+        info.update({"components": int(len(uniq)), "cc_iterations": cc_iters,
+                     "moved_points": int((dpt != rank).sum().item())})
+        t0 = tick("redistribute_ms", t0)
+    else:
+        g_own, g_ng, g_nr = own, neigh, normals
+        info.update({"components": None, "cc_iterations": 0, "moved_points": 0})
+    # local cloud in ascending GLOBAL index order: "the earlier seed wins" means the same thing locally
+    sg, perm = torch.sort(g_own[:, 3])
+    n_loc = int(sg.shape[0])
+    tot = torch.tensor([n_loc], dtype=torch.int64, device=dev)
+    all_reduce_(tot, dist.ReduceOp.SUM, group)
+    err = None
+    labels_l = owner_l = seeds_l = None
+    planes_fn = None
+    try:
+        if int(tot.item()) != n_total or (n_loc and bool((sg[1:] == sg[:-1]).any().item())):
+            raise RuntimeError("the shards do not cover the cloud exactly once "
+                               f"({int(tot.item())} points arrived, n_total = {n_total})")
+        xyz_l = g_own[perm, :3].contiguous()
+        nr_l = g_nr[perm].contiguous()
+        identity = n_loc == n_total and (not _live(group))
+        if identity and bool((sg == torch.arange(n_total, dtype=sg.dtype, device=dev)).all().item()):
+            ng_l = g_ng[perm].contiguous()  # global ids ARE the local ones
+        else:
+            ng_l, miss = backend.remap_rows(g_ng[perm].contiguous(), sg.contiguous())
+            if miss:
+                raise RuntimeError("a k-list refers to a point outside its connected component")
+        del g_own, g_ng, g_nr
+        t0 = tick("localize_ms", t0)
+        if n_loc >= k:
+            labels_l, owner_l, seeds_l, planes_fn = backend.region_grow(xyz_l, nr_l, ng_l, params)
+        elif n_loc:
+            raise RuntimeError(f"{n_loc} points in a shard, fewer than k = {k}")
+    except Exception as e:  # noqa: BLE001 -- agreed on by all ranks below
+        err = e
+    _agree(err, "region growing", dev, group)
+    t0 = tick("grow_ms", t0)
+    if n_loc < k:
+        owner_g = torch.full((n_loc,), -1, dtype=torch.int32, device=dev)
+        seeds_g = torch.zeros((0,), dtype=torch.int32, device=dev)
+    else:
+        owner_g = torch.where(owner_l >= 0, sg[owner_l.clamp(min=0).to(torch.int64)], torch.full_like(owner_l, -1))
+        seeds_g = sg[seeds_l.to(torch.int64)] if seeds_l.shape[0] else sg[:0]
+    # global plane ids: rank of the seed among ALL committed seeds (cur_planeId advances once per commit)
+    all_seeds = torch.sort(all_gather_var(seeds_g.contiguous(), group)[0]).values.contiguous()
+    labels = torch.full((n_total,), -1, dtype=torch.int32, device=dev)
+    if n_loc:
+        labels[sg.to(torch.int64)] = backend.labels_from_owner(owner_g.contiguous(), all_seeds)
+    all_reduce_(labels, dist.ReduceOp.MAX, group)  # every point has exactly one owner rank; the others hold -1
+    info["n_grow"] = n_loc
+    info["n_planes_total"] = int(all_seeds.shape[0])
+    planes = None
+    if want_planes:
+        planes = []
+        if planes_fn is not None and n_loc >= k:
+            sg_h = sg.cpu().numpy()
+            seeds_h = all_seeds.cpu().numpy()
+            for pl in _iter_planes(planes_fn()):
+                gl = sg_h[pl["pointIdx"]]
+                planes.append({"id": int(1 + np.searchsorted(seeds_h, gl[0])), "normal": pl["normal"], "center": pl["center"],
+                               "pointIdx": gl.astype(np.int32)})
+    t0 = tick("labels_ms", t0)
+    return labels, planes, info, t0
+
+
+def _iter_planes(pl):
+    """Plane records of either backend as dicts (api.Plane list, or the oracle's CSR dict)."""
+    if pl is None:
+        return
+    if isinstance(pl, dict):
+        off = pl["offset"]
+        for i in range(len(pl["id"])):
+            yield {"normal": pl["normal"][i], "center": pl["center"][i], "pointIdx": pl["point_idx"][off[i]:off[i + 1]]}
+    else:
+        for p in pl:
+            yield {"normal": p.normal, "center": p.center, "pointIdx": p.pointIdx}
+
+
+def gather_planes(planes, group=None):
+    """All ranks' plane records on every rank, in plane-id order (host objects; for tests and the CLI adapter --
+    the measured path keeps the records on the device that grew them)."""
+    if not _live(group):
+        return sorted(planes, key=lambda p: p["id"])
+    box = [None] * _world(group)
+    dist.all_gather_object(box, planes, group=group)
+    return sorted([p for part in box for p in part], key=lambda p: p["id"])
+
+
 def segment_sharded_dev(backend, d_xyz: torch.Tensor, d_gidx: torch.Tensor, n_total: int, params, halo: float = 0.0,
-                        group=None, max_retries: int = 6, grow: bool = True):
+                        group=None, max_retries: int = 6, grow: bool = True, want_planes: bool = False):
     """Segment ONE cloud whose points are spread over the ranks (any split; rank r passes its
     points `d_xyz` int32 [m,3] and their global indices `d_gidx` int32 [m], resident on its device).
 
     Returns (labels, info): labels = int32 [n_total] tensor, identical on every rank (None if
     grow=False); info carries the slab results (`gidx_own`, `neigh_own`, `normals_own`: this
-    rank's Morton slab), `planes` (rank 0 only -- stage 3 is "replicas only", the other ranks
-    get None), the halo width used, the retries and per-stage wall times."""
+    rank's Morton slab), `planes` (want_planes: the planes THIS rank grew, with global ids and global
+    point indices -- gather_planes() collects them), the halo width used, the retries and per-stage
+    wall times."""
     if hasattr(backend, "knn_normals_dev"):  # an api.Context: wrap it
         backend = DevBackend(backend)
     world, rank = _world(group), _rank(group)
@@ -282,12 +542,17 @@ def segment_sharded_dev(backend, d_xyz: torch.Tensor, d_gidx: torch.Tensor, n_to
         xyz_loc = loc[:, :3].contiguous()
         gidx_loc = loc[:, 3].contiguous()
         t0 = tick("halo_ms", t0)
-        if n_own and xyz_loc.shape[0] >= k:
-            neigh, normals, unc = backend.knn_normals(xyz_loc, gidx_loc, n_own, params, h if world > 1 else 0.0)
-        else:  # a slab that cannot even fill one k-list: force a wider halo (or fail below)
-            neigh = torch.zeros((n_own, k), dtype=torch.int32, device=dev)
-            normals = torch.zeros((n_own, 3), dtype=torch.float64, device=dev)
-            unc = n_own
+        err, unc = None, 0
+        try:
+            if n_own and xyz_loc.shape[0] >= k:
+                neigh, normals, unc = backend.knn_normals(xyz_loc, gidx_loc, n_own, params, h if world > 1 else 0.0)
+            else:  # a slab that cannot even fill one k-list: force a wider halo (or fail below)
+                neigh = torch.zeros((n_own, k), dtype=torch.int32, device=dev)
+                normals = torch.zeros((n_own, 3), dtype=torch.float64, device=dev)
+                unc = n_own
+        except Exception as e:  # noqa: BLE001 -- agreed on by all ranks below
+            err = e
+        _agree(err, "kNN + normals", dev, group)
         t0 = tick("knn_normals_ms", t0)
         flag = torch.tensor([unc], dtype=torch.int64, device=dev)
         all_reduce_(flag, dist.ReduceOp.MAX, group)
@@ -295,45 +560,18 @@ def segment_sharded_dev(backend, d_xyz: torch.Tensor, d_gidx: torch.Tensor, n_to
             break
         retries += 1
         if retries > max_retries or world == 1:
-            raise RuntimeError("halo exchange could not certify every k-list "
-                               f"(halo {h} mm after {retries - 1} doublings; n_total={n_total}, k={k})")
+            raise ShardError("halo exchange could not certify every k-list "
+                             f"(halo {h} mm after {retries - 1} doublings; n_total={n_total}, k={k})")
         h *= 2.0  # a thin halo is a performance matter, never a correctness one
     info = {"halo": h, "retries": retries, "n_local": int(xyz_loc.shape[0]), "n_own": n_own,
             "gidx_own": own[:, 3].contiguous(), "neigh_own": neigh, "normals_own": normals, "planes": None}
     labels = None
-    st["gather_ms"] = st["grow_ms"] = 0.0
+    for kk in ("components_ms", "redistribute_ms", "localize_ms", "grow_ms", "labels_ms"):
+        st[kk] = 0.0
     if grow:
-        # stage 3, replicas only: the graph goes to rank 0 (the only receiver), which grows and broadcasts
-        if world > 1:
-            to0 = torch.zeros(world, dtype=torch.int64, device=dev)
-            to0[0] = n_own
-            g_own, _ = all_to_all_rows(own, to0, group)
-            g_ng, _ = all_to_all_rows(neigh, to0, group)
-            g_nr, _ = all_to_all_rows(normals, to0, group)
-        else:
-            g_own, g_ng, g_nr = own, neigh, normals
-        labels = torch.empty(n_total, dtype=torch.int32, device=dev)
-        if rank == 0:
-            gi = g_own[:, 3].to(torch.int64)
-            if g_own.shape[0] != n_total or int(torch.unique(gi).shape[0]) != n_total:
-                raise RuntimeError("partition must cover the cloud exactly once")
-            xyz_all = torch.empty((n_total, 3), dtype=torch.int32, device=dev)
-            neigh_all = torch.empty((n_total, k), dtype=torch.int32, device=dev)
-            normals_all = torch.empty((n_total, 3), dtype=torch.float64, device=dev)
-            xyz_all[gi] = g_own[:, :3]
-            neigh_all[gi] = g_ng
-            normals_all[gi] = g_nr
-            del g_own, g_ng, g_nr
-            t0 = tick("gather_ms", t0)
-            lab, planes = backend.region_grow(xyz_all, normals_all, neigh_all, params)
-            labels.copy_(lab)
-            info["planes"] = planes
-            t0 = tick("grow_ms", t0)
-        if world > 1:
-            c = _coll(labels, group)
-            dist.broadcast(c, src=0, group=group)
-            if c is not labels:
-                labels.copy_(c)
-        t0 = tick("gather_ms" if rank else "grow_ms", t0)
+        labels, planes, ginfo, t0 = _grow_components(backend, own, neigh, normals, n_total, params, group, st, tick, t0,
+                                                     want_planes)
+        info.update(ginfo)
+        info["planes"] = planes
     info["stage_ms"] = st
     return labels, info

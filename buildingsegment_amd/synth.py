@@ -138,6 +138,28 @@ def urban(n_target: int, seed: int = 3, shuffle: bool = True, spacing: int = 50,
     return _finish(pts, seed, shuffle)
 
 
+def boxes(n_boxes: int = 6, seed: int = 21, spacing: int = 50, edge_lo: int = 30, edge_hi: int = 60, pitch: int = 6000,
+          shuffle: bool = True) -> np.ndarray:
+    """Small multi-building scene for the sharded-path tests: n_boxes separate box "buildings" (four walls + roof,
+    edges of edge_lo..edge_hi samples @spacing, C1 noise model) on a row/column grid with `pitch` mm between
+    origins -- far enough apart that every box is its own connected component of the kNN graph."""
+    faces = []
+    side = max(int(np.ceil(np.sqrt(n_boxes))), 1)
+    for b in range(n_boxes):
+        u = _uniform(seed, 2000 + b, 3)
+        ax, ay, hz = (int(edge_lo + u[t] * (edge_hi - edge_lo)) for t in range(3))
+        o = np.array([(b % side) * pitch, (b // side) * pitch, 0])
+        ex, ey, ez = ax * spacing, ay * spacing, hz * spacing
+        specs = [
+            (o, (1, 0, 0), (0, 0, 1), ax, hz), (o + (0, ey, 0), (1, 0, 0), (0, 0, 1), ax, hz),
+            (o, (0, 1, 0), (0, 0, 1), ay, hz), (o + (ex, 0, 0), (0, 1, 0), (0, 0, 1), ay, hz),
+            (o + (0, 0, ez), (1, 0, 0), (0, 1, 0), ax, ay),
+        ]
+        for t, (org, eu, ev, nu, nv) in enumerate(specs):
+            faces.append(_face(org, eu, ev, nu, nv, spacing, seed, 300 + b * 8 + t))
+    return _finish(np.concatenate(faces), seed, shuffle)
+
+
 def uniform(n: int, seed: int = 6) -> np.ndarray:
     """U: n integer points i.i.d. uniform in [0, L)^3, L = round(50 * n^(1/3)) mm."""
     L = int(round(50.0 * n ** (1.0 / 3.0)))

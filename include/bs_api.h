@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BS_API_VERSION 3
+#define BS_API_VERSION 4
 
 typedef enum bs_status {
   BS_OK = 0,
@@ -255,6 +255,43 @@ int bs_set_audit(bs_ctx* ctx, int on);
 
 /* Copy the plane records of the last region-grow on this context to the host. */
 int bs_planes_fetch(bs_ctx* ctx, bs_planes* planes);
+
+/* ---- building blocks of the multi-GPU path (component-sharded stage 3) ----
+ *
+ * The reference's seed scan (my_function.cpp:184-217) is global, but information only travels along kNN edges
+ * (Broad tests neigh[Idx][1..K-1], :224-233; a failed seed labels part of its own row, :238-239): connected
+ * components of the kNN graph never interact, and the only shared state is cur_planeId, which advances once per
+ * committed plane (:199-202), i.e.
+ *     planeIdx[p] = 1 + #(committed seeds < owner[p]),   owner[p] = the seed attempt that left p labelled.
+ * So stage 3 shards exactly: whole components per GPU (local cloud in ascending global index order), committed
+ * seeds all-gathered, labels from the owners.  buildingsegment_amd/dist.py (torch.distributed) and
+ * bs_segment_sharded (RCCL, below) are built from these calls.
+ *
+ * bs_cc_hook_dev: one hooking step of a distributed union-find.  d_parent [n_total] (device, in/out) is a parent
+ *   array over GLOBAL point ids with parent[x] <= x (start: identity).  The call unites u = d_gidx[i] (NULL: i) with
+ *   every d_rows[i][j] (global ids, [m][k]) and points every node it touched straight at its root.  *n_hooks (host)
+ *   = unions performed.  Multi-GPU: every rank hooks its own rows, the parent arrays are all-reduced with MIN, and
+ *   the step repeats until no rank hooked anything; then parent[x] = smallest global id of x's component.
+ *   Synchronises.
+ * bs_owner_fetch_dev: d_owner [n] (device) receives, in the caller's index order, the seed index of the attempt
+ *   that left each point labelled after the last bs_region_grow[_dev] / bs_segment[_dev] on this context (-1:
+ *   unlabelled).  rg_mode 0 / 2 only (the single-wave grower keeps no owners: BS_ERR_INVALID).
+ * bs_labels_from_owner_dev: d_plane_idx[i] = d_owner[i] < 0 ? -1 : 1 + #(d_seeds[] < d_owner[i]); d_seeds is the
+ *   ascending list of ALL committed seeds (global indices), d_owner holds global seed indices.
+ * bs_remap_rows_dev: d_out[t] = position of d_rows[t] in the ascending array d_sorted_gidx [n] (global -> local
+ *   index of a component-complete local cloud); *n_missing (host) != 0 if some index was not found.  Synchronises. */
+int bs_cc_hook_dev(bs_ctx* ctx, const int32_t* d_rows, const int32_t* d_gidx, int64_t m, int32_t k, int32_t* d_parent,
+                   int64_t n_total, int64_t* n_hooks);
+int bs_owner_fetch_dev(bs_ctx* ctx, int32_t* d_owner);
+/* bs_plane_seeds_dev: the seeds (= pointIdx[0], my_function.cpp:191) of the planes the last speculative grow on this
+ *   context committed, ascending (= commit order); *n_planes (host) receives their number, at most cap of them are
+ *   copied to d_seeds (device, nullable).  bs_stream_sync: wait for everything enqueued on the context's stream. */
+int bs_plane_seeds_dev(bs_ctx* ctx, int32_t* d_seeds, int64_t cap, int32_t* n_planes);
+int bs_stream_sync(bs_ctx* ctx);
+int bs_labels_from_owner_dev(bs_ctx* ctx, const int32_t* d_owner, int64_t n, const int32_t* d_seeds, int32_t n_seeds,
+                             int32_t* d_plane_idx);
+int bs_remap_rows_dev(bs_ctx* ctx, const int32_t* d_rows, int64_t n_rows, int32_t k, const int32_t* d_sorted_gidx,
+                      int64_t n, int32_t* d_out, int32_t* n_missing);
 
 #ifdef __cplusplus
 }

@@ -622,14 +622,20 @@ static int ivec_push(ivec* a, int32_t x)
   return 0;
 }
 
-int bso_region_grow(const int32_t* xyz, const double* normals, const int32_t* neigh, int64_t n,
-                    int k, int th_thickness, int th_point_count, double cos_th,
-                    int32_t* plane_idx, bso_planes* planes, int64_t* n_seed_attempts)
+/* owner (nullable) [n]: index of the seed attempt that left the point labelled (-1: unlabelled).  Not a
+ * reference output: plane_idx[p] == 1 + #(committed seeds < owner[p]) (cur_planeId only advances on commit,
+ * my_function.cpp:199-202), which is how a sharded run turns per-shard results into the global ids. */
+static int region_grow_core(const int32_t* xyz, const double* normals, const int32_t* neigh, int64_t n,
+                            int k, int th_thickness, int th_point_count, double cos_th,
+                            int32_t* plane_idx, bso_planes* planes, int64_t* n_seed_attempts, int32_t* owner)
 {
   if (!xyz || !normals || !neigh || !plane_idx || n <= 0 || k < 1 || n < k)
     return -1;
   for (int64_t i = 0; i < n; i++)
     plane_idx[i] = -1; /* my_function.h:103 */
+  if (owner)
+    for (int64_t i = 0; i < n; i++)
+      owner[i] = -1;
   ivec list = {0, 0, 0};  /* cur_plane.pointIdx */
   ivec stack = {0, 0, 0}; /* pending Broad(id, depth+1) calls, LIFO */
   ivec all = {0, 0, 0};   /* committed lists, concatenated */
@@ -681,6 +687,8 @@ int bso_region_grow(const int32_t* xyz, const double* normals, const int32_t* ne
               break;
             }
             plane_idx[id] = cur_plane_id;
+            if (owner)
+              owner[id] = (int32_t)i;
             S[0] += m[0];
             S[1] += m[1];
             S[2] += m[2];
@@ -745,8 +753,11 @@ int bso_region_grow(const int32_t* xyz, const double* normals, const int32_t* ne
       np++;
       cur_plane_id++;
     } else {
-      for (int64_t t = 0; t < list.n; t++) /* :203-208 */
+      for (int64_t t = 0; t < list.n; t++) { /* :203-208 */
         plane_idx[list.v[t]] = -1;
+        if (owner)
+          owner[list.v[t]] = -1;
+      }
     }
   }
   free(list.v);
@@ -779,6 +790,22 @@ int bso_region_grow(const int32_t* xyz, const double* normals, const int32_t* ne
     free(pc);
   }
   return 0;
+}
+
+int bso_region_grow(const int32_t* xyz, const double* normals, const int32_t* neigh, int64_t n,
+                    int k, int th_thickness, int th_point_count, double cos_th,
+                    int32_t* plane_idx, bso_planes* planes, int64_t* n_seed_attempts)
+{
+  return region_grow_core(xyz, normals, neigh, n, k, th_thickness, th_point_count, cos_th, plane_idx, planes,
+                          n_seed_attempts, NULL);
+}
+
+int bso_region_grow_owner(const int32_t* xyz, const double* normals, const int32_t* neigh, int64_t n,
+                          int k, int th_thickness, int th_point_count, double cos_th,
+                          int32_t* plane_idx, bso_planes* planes, int64_t* n_seed_attempts, int32_t* owner)
+{
+  return region_grow_core(xyz, normals, neigh, n, k, th_thickness, th_point_count, cos_th, plane_idx, planes,
+                          n_seed_attempts, owner);
 }
 
 void bso_planes_free(bso_planes* p)

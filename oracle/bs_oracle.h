@@ -63,6 +63,13 @@ int bso_region_grow(const int32_t* xyz, const double* normals, const int32_t* ne
                     int k, int th_thickness, int th_point_count, double cos_th,
                     int32_t* plane_idx, bso_planes* planes, int64_t* n_seed_attempts);
 
+/* The same, additionally reporting owner[p] = index of the seed attempt that left p labelled (-1: none):
+ * plane_idx[p] == 1 + #(committed seeds < owner[p]).  Checker of bs_owner_fetch_dev and of the
+ * component-sharded stage 3 (buildingsegment_amd/dist.py). */
+int bso_region_grow_owner(const int32_t* xyz, const double* normals, const int32_t* neigh, int64_t n,
+                          int k, int th_thickness, int th_point_count, double cos_th,
+                          int32_t* plane_idx, bso_planes* planes, int64_t* n_seed_attempts, int32_t* owner);
+
 void bso_planes_free(bso_planes* planes);
 
 double bso_det_acos(double x);

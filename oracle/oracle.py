@@ -41,6 +41,8 @@ def lib():
         L.bso_fast_eigen3x3.argtypes = [dp, dp]
         L.bso_region_grow.argtypes = [ip, dp, ip, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double,
                                       ip, C.POINTER(_Planes), lp]
+        L.bso_region_grow_owner.argtypes = [ip, dp, ip, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double,
+                                            ip, C.POINTER(_Planes), lp, ip]
         L.bso_planes_free.argtypes = [C.POINTER(_Planes)]
         L.bso_det_acos.argtypes = [C.c_double]
         L.bso_det_acos.restype = C.c_double
@@ -116,21 +118,29 @@ def _planes_to_py(P):
                           if off[-1] > 0 else np.zeros(0, np.int32))}
 
 
-def region_grow(xyz, normals, neigh, th_thickness=300, th_point_count=400, cos_th=0.88):
+def region_grow(xyz, normals, neigh, th_thickness=300, th_point_count=400, cos_th=0.88, want_owner=False):
+    """(plane_idx, planes) -- with want_owner also owner [n]: the seed attempt that left each point labelled."""
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)
     normals = np.ascontiguousarray(normals, dtype=np.float64)
     neigh = np.ascontiguousarray(neigh, dtype=np.int32)
     n, k = neigh.shape
     plane_idx = np.empty(n, dtype=np.int32)
+    owner = np.empty(n, dtype=np.int32) if want_owner else None
     P = _Planes()
     att = C.c_int64(0)
-    rc = lib().bso_region_grow(_ip(xyz), _dp(normals), _ip(neigh), n, k, th_thickness, th_point_count,
-                               cos_th, _ip(plane_idx), C.byref(P), C.byref(att))
+    if want_owner:
+        rc = lib().bso_region_grow_owner(_ip(xyz), _dp(normals), _ip(neigh), n, k, th_thickness, th_point_count,
+                                         cos_th, _ip(plane_idx), C.byref(P), C.byref(att), _ip(owner))
+    else:
+        rc = lib().bso_region_grow(_ip(xyz), _dp(normals), _ip(neigh), n, k, th_thickness, th_point_count,
+                                   cos_th, _ip(plane_idx), C.byref(P), C.byref(att))
     if rc != 0:
         raise ValueError(f"bso_region_grow failed: {rc}")
     planes = _planes_to_py(P)
     planes["n_seed_attempts"] = att.value
     lib().bso_planes_free(C.byref(P))
+    if want_owner:
+        return plane_idx, planes, owner
     return plane_idx, planes
 
 

@@ -1,8 +1,10 @@
-"""N>1 path on CPU: world_size-2/3 gloo runs of buildingsegment_amd.dist.segment_sharded_dev
+"""N>1 path on CPU: world_size-2/3/5 gloo runs of buildingsegment_amd.dist.segment_sharded_dev
 with the CPU oracle injected as compute backend (the HIP backend needs a GPU).  The
 orchestration under test is the SAME code bench.py --gpus N runs on device tensors: Morton
-partition (all-to-all), voxel halo (all-to-all), certification + retry, graph to rank 0,
-rank-0 region grow, label broadcast."""
+partition (all-to-all), voxel halo (all-to-all), certification + retry, distributed
+union-find (all-reduce MIN), component deal + redistribution (all-to-all), per-rank region
+growing of whole components, global plane ids from the all-gathered committed seeds, label
+all-reduce; plus the agreement on failures (no rank may be left waiting in a collective)."""
 import os
 import socket
 import sys
@@ -17,13 +19,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleBackend:
-    """Slab semantics of bs_knn_normals_dev(d_gidx, cert_radius) restated with the CPU oracle:
-    ties by GLOBAL index (local cloud sorted by gidx first), global indices out,
+    """CPU restatement of the backend contract of buildingsegment_amd.dist (see its docstring).
+    Slab kNN: ties by GLOBAL index (local cloud sorted by gidx first), global indices out,
     certification = k-th distance < cert_radius."""
 
-    def __init__(self):
+    def __init__(self, fail_grow_on_rank=None):
         from oracle import oracle as O
         self.O = O
+        self.fail_grow_on_rank = fail_grow_on_rank
 
     def knn_normals(self, xyz_loc, gidx_loc, n_query, params, cert_radius):
         xyz_local, gidx = xyz_loc.numpy(), gidx_loc.numpy()
@@ -40,10 +43,50 @@ class OracleBackend:
             unc = int(((d * d).sum(1) >= cert_radius * cert_radius).sum())
         return torch.from_numpy(gs[ngq].astype(np.int32)), torch.from_numpy(nrq), unc
 
+    def cc_hook(self, rows, gidx, parent):
+        """bs_cc_hook_dev restated with numpy (vectorised hooking + pointer jumping)."""
+        P = parent.numpy()  # shares the tensor's memory: updated in place
+        u = np.repeat(gidx.numpy().astype(np.int64), rows.shape[1])
+        v = rows.numpy().reshape(-1).astype(np.int64)
+
+        def find(x):
+            r = P[x].astype(np.int64)
+            while True:
+                rr = P[r].astype(np.int64)
+                if (rr == r).all():
+                    return r
+                r = rr
+
+        hooks = 0
+        while True:
+            ru, rv = find(u), find(v)
+            m = ru != rv
+            if not m.any():
+                break
+            hi, lo = np.maximum(ru[m], rv[m]), np.minimum(ru[m], rv[m])
+            np.minimum.at(P, hi, lo.astype(P.dtype))
+            hooks += len(np.unique(hi))
+        touched = np.unique(np.concatenate([u, v]))
+        P[touched] = find(touched).astype(P.dtype)
+        return hooks
+
+    def remap_rows(self, rows, sorted_gidx):
+        sg, r = sorted_gidx.numpy(), rows.numpy()
+        pos = np.searchsorted(sg, r)
+        ok = (pos < len(sg)) & (sg[np.minimum(pos, len(sg) - 1)] == r)
+        return torch.from_numpy(np.where(ok, pos, 0).astype(np.int32)), int((~ok).any())
+
     def region_grow(self, xyz, normals, neigh, params):
-        pi, pl = self.O.region_grow(xyz.numpy(), normals.numpy(), neigh.numpy(), th_thickness=params.th_thickness,
-                                    th_point_count=params.th_point_count, cos_th=params.cos_th)
-        return torch.from_numpy(pi), pl
+        if self.fail_grow_on_rank is not None and dist.get_rank() == self.fail_grow_on_rank:
+            raise RuntimeError("injected failure")
+        pi, pl, ow = self.O.region_grow(xyz.numpy(), normals.numpy(), neigh.numpy(), th_thickness=params.th_thickness,
+                                        th_point_count=params.th_point_count, cos_th=params.cos_th, want_owner=True)
+        seeds = pl["point_idx"][pl["offset"][:-1]].astype(np.int32)
+        return torch.from_numpy(pi), torch.from_numpy(ow), torch.from_numpy(seeds), (lambda: pl)
+
+    def labels_from_owner(self, owner, seeds):
+        o, s = owner.numpy(), seeds.numpy()
+        return torch.from_numpy(np.where(o >= 0, 1 + np.searchsorted(s, o, side="left"), -1).astype(np.int32))
 
 
 def _free_port():
@@ -60,48 +103,98 @@ def _params(k=15):
                        cell_size=0, rg_mode=0)
 
 
-def _worker(rank, world, port, halo, out):
+def _cloud(name):
+    from buildingsegment_amd import synth
+    return synth.plane_cube()[:24000].copy() if name == "plane_cube" else synth.boxes()
+
+
+def _worker(rank, world, port, halo, out, cloud, fail_rank):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from buildingsegment_amd import dist as bsd, synth
-    xyz = synth.plane_cube()[:24000].copy()
+    from buildingsegment_amd import dist as bsd
+    xyz = _cloud(cloud)
     n = len(xyz)
     b = bsd.slab_bounds(n, world)  # the input split is arbitrary: a contiguous 1/N of the input order
     d_xyz = torch.from_numpy(xyz[b[rank]:b[rank + 1]])
     d_gidx = torch.arange(b[rank], b[rank + 1], dtype=torch.int32)
-    labels, info = bsd.segment_sharded_dev(OracleBackend(), d_xyz, d_gidx, n, _params(), halo=halo)
+    try:
+        labels, info = bsd.segment_sharded_dev(OracleBackend(fail_rank), d_xyz, d_gidx, n, _params(), halo=halo, want_planes=True)
+    except bsd.ShardError as e:
+        open(out % rank + ".err", "w").write(str(e))
+        dist.destroy_process_group()
+        return
+    planes = bsd.gather_planes(info["planes"])
     np.savez(out % rank, idx=info["gidx_own"].numpy(), ng=info["neigh_own"].numpy(), nr=info["normals_own"].numpy(),
-             labels=labels.numpy(), retries=info["retries"], n_local=info["n_local"],
-             nplanes=-1 if info["planes"] is None else len(info["planes"]["id"]))
+             labels=labels.numpy(), retries=info["retries"], n_local=info["n_local"], n_grow=info["n_grow"],
+             components=info["components"], cc_iterations=info["cc_iterations"],
+             pid=np.array([p["id"] for p in planes], np.int32),
+             pnormal=np.array([p["normal"] for p in planes], np.float64).reshape(-1, 3),
+             pcenter=np.array([p["center"] for p in planes], np.int32).reshape(-1, 3),
+             poff=np.cumsum([0] + [len(p["pointIdx"]) for p in planes]),
+             pidx=np.concatenate([p["pointIdx"] for p in planes]) if planes else np.zeros(0, np.int32))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo", [(2, 250.0), (2, 30.0), (3, 200.0), (5, 150.0)])
-def test_sharded_run_equals_single_process(oracle, tmp_path, world, halo):
-    from buildingsegment_amd import synth
+@pytest.mark.parametrize("world,halo,cloud", [(2, 250.0, "plane_cube"), (2, 30.0, "plane_cube"), (3, 200.0, "boxes"),
+                                              (2, 250.0, "boxes"), (5, 150.0, "boxes")])
+def test_sharded_run_equals_single_process(oracle, tmp_path, world, halo, cloud):
     out = str(tmp_path / "r%d.npz")
-    mp.spawn(_worker, args=(world, _free_port(), halo, out), nprocs=world, join=True)
-    xyz = synth.plane_cube()[:24000].copy()
+    mp.spawn(_worker, args=(world, _free_port(), halo, out, cloud, None), nprocs=world, join=True)
+    xyz = _cloud(cloud)
     ng, nr = oracle.knn_normals(xyz, k=15)
     pi, pl = oracle.region_grow(xyz, nr, ng)
     seen = np.zeros(len(xyz), int)
-    sizes = []
+    sizes, grown = [], []
     for r in range(world):
         g = np.load(out % r)
         assert np.array_equal(g["ng"], ng[g["idx"]])      # neighbour indices bit-exact
         assert np.array_equal(g["nr"], nr[g["idx"]])      # normals bit-exact
-        assert np.array_equal(g["labels"], pi)            # labels identical on every rank
+        assert np.array_equal(g["labels"], pi)            # labels identical on every rank, equal to the sequential scan
         assert g["n_local"] < len(xyz)                    # a slab + halo, not the whole cloud
-        assert g["nplanes"] == (len(pl["id"]) if r == 0 else -1)  # stage 3: replicas only, planes on rank 0
+        # plane records (gathered): ids, lists (order and duplicates), centres and normals bit for bit
+        assert np.array_equal(g["pid"], pl["id"])
+        assert np.array_equal(g["poff"], pl["offset"]) and np.array_equal(g["pidx"], pl["point_idx"])
+        assert np.array_equal(g["pcenter"], pl["center"])
+        assert np.array_equal(g["pnormal"].view(np.int64), pl["normal"].view(np.int64))
         seen[g["idx"]] += 1
         sizes.append(len(g["idx"]))
+        grown.append(int(g["n_grow"]))
         if halo < 100:
             assert g["retries"] >= 1                      # halo below the hybrid radius is widened
     assert (seen == 1).all()                              # the Morton slabs partition the cloud
     assert max(sizes) < 1.25 * len(xyz) / world           # ... into nearly equal counts
+    assert sum(grown) == len(xyz)                         # stage 3: every point grown by exactly one rank
+    if cloud == "boxes":
+        assert int(g["components"]) == 6 and sum(1 for v in grown if v > 0) >= min(world, 2)  # the boxes are spread
+
+
+def test_failure_on_one_rank_is_raised_on_every_rank(tmp_path):
+    """A compute failure on rank 0 (here: injected into region growing) must not leave the other ranks waiting in
+    the next collective: all of them raise ShardError."""
+    world = 2
+    out = str(tmp_path / "r%d.npz")
+    mp.spawn(_worker, args=(world, _free_port(), 250.0, out, "boxes", 0), nprocs=world, join=True)
+    msgs = [open(out % r + ".err").read() for r in range(world)]
+    assert "injected failure" in msgs[0] and "another rank failed in region growing" in msgs[1]
+
+
+def test_component_deal_is_balanced_and_prefers_home():
+    from buildingsegment_amd import dist as bsd
+    # 4 components of 100 points on ranks {0: c0 + c1, 1: c2 + half of c3, 2: half of c3}; 1 component split 50 / 50
+    roots = np.array([10, 20, 30, 40, 40])
+    counts = np.array([100, 100, 100, 60, 40])
+    ranks = np.array([0, 0, 1, 1, 2])
+    uniq, dest = bsd.assign_components(roots, counts, ranks, 3)
+    load = np.bincount(dest, weights=[100, 100, 100, 100], minlength=3)
+    assert uniq.tolist() == [10, 20, 30, 40]
+    assert load.max() <= 200 and dest[0] == 0  # the first component stays at home; nobody holds more than two
+    assert np.array_equal(dest, bsd.assign_components(roots[::-1], counts[::-1], ranks[::-1], 3)[1])  # order-independent
+    # one giant component: it stays where most of it is, whatever the balance
+    uniq, dest = bsd.assign_components(np.array([7, 7]), np.array([10, 990]), np.array([0, 1]), 2)
+    assert dest.tolist() == [1]
 
 
 def test_single_process_path_without_process_group(oracle):
