@@ -12,14 +12,16 @@ the same protocol, each with its own `roofline` block.
 
 N > 1 (`--gpus N`, one rank per GPU over RCCL): ONE urban_50m cloud is segmented
 by buildingsegment_amd.dist.segment_sharded_dev -- stages 1-2 sharded by Morton
-slabs with a device-resident halo exchange, stage 3 "replicas only" (rank 0
-grows, labels are broadcast) -- strong scaling, stage times reported separately.
+slabs with a device-resident halo exchange, stage 3 sharded exactly by connected
+components of the kNN graph (union-find all-reduce, per-rank growth, global plane
+ids from the all-gathered committed seeds) -- strong scaling, stage times reported
+separately.
 `python bench.py --gpus N` without a launcher starts the N ranks itself (before
 anything touches the GPU); under torchrun WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line (rank 0): the driver's contract fields plus `roofline`
 (dominant kernel: algorithmic bytes / HIP-event launch time on the launch stream)
-and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
+and `cpu_baseline` (the CPU oracle timed on this box's host cores by rank 0).
 """
 from __future__ import annotations
 
@@ -383,7 +385,8 @@ def main():
             out["concurrent_clouds"] = measure_concurrent(api, torch, dev, args.workload, args.k, args.rg_mode, args.steps,
                                                           args.concurrent)
     else:
-        # ONE cloud sharded over the ranks (north_star: Morton slabs + halo exchange); stage 3 replicas only
+        # ONE cloud sharded over the ranks (north_star: Morton slabs + halo exchange + label union-find all-reduce):
+        # stages 1-2 by Morton slabs, stage 3 by connected components of the kNN graph (exact; dist.py)
         from buildingsegment_amd import dist as bsd
         xyz, k = make_cloud(args.workload)
         if args.k:
@@ -392,11 +395,16 @@ def main():
         params = api.default_params(k=k, rg_mode=args.rg_mode)
         b = bsd.slab_bounds(n, world)
         # resident input: rank r holds the r-th 1/N of the cloud in INPUT order (+ the global indices);
-        # the Morton partition, the halo exchange and every gather are inside the timed region
+        # the Morton partition, the halo exchange and every other exchange are inside the timed region
         d_own = torch.from_numpy(xyz[b[rank]:b[rank + 1]]).to(dev)
         d_gidx = torch.arange(b[rank], b[rank + 1], dtype=torch.int32, device=dev)
-        del xyz
-        st = {"partition_ms": 0.0, "halo_ms": 0.0, "knn_normals_ms": 0.0, "gather_ms": 0.0, "grow_ms": 0.0}
+        if rank != 0 or args.no_cpu_baseline:
+            del xyz
+        keys = ["partition_ms", "halo_ms", "knn_normals_ms", "components_ms", "redistribute_ms", "localize_ms", "grow_ms",
+                "labels_ms"]
+        st = {kk: 0.0 for kk in keys}
+        kst = {"grid_ms": 0.0, "knn_ms": 0.0, "grow_kernel_ms": 0.0, "grow_setup_ms": 0.0}
+        launches = 0
         info = {}
         for _ in range(args.warmup):
             bsd.segment_sharded_dev(ctx, d_own, d_gidx, n, params)
@@ -406,22 +414,44 @@ def main():
             _, info = bsd.segment_sharded_dev(ctx, d_own, d_gidx, n, params)
             for kk in st:
                 st[kk] += info["stage_ms"][kk]
+            tm = ctx.timings()  # HIP-event times of this rank's kNN and growth kernels in this step
+            for kk in kst:
+                kst[kk] += tm.get(kk, 0.0)
+            launches += tm["grow_kernel_launches"]
         fence()
         elapsed = all_reduce_max(time.perf_counter() - t0)
         for kk in st:
             st[kk] = all_reduce_max(st[kk] / max(args.steps, 1))
+        n_grow_max = int(all_reduce_max(float(info.get("n_grow", 0))))
         if rank == 0:
+            for kk in kst:
+                kst[kk] /= max(args.steps, 1)
+            # roofline of rank 0's dominant kernel: its own share of the work (n_own queries / n_grow grown points)
+            stage0 = {"knn_ms": kst["knn_ms"], "grow_kernel_ms": kst["grow_kernel_ms"]}
+            n_knn, n_grow = int(info.get("n_own", 0)), int(info.get("n_grow", 0))
+            lps = launches / max(args.steps, 1)
+            if kst["grow_kernel_ms"] >= kst["knn_ms"] and n_grow:
+                roof = roofline_block(n_grow, k, stage0, lps, args.rg_mode, "")
+            else:
+                roof = roofline_block(n_knn, k, {"knn_ms": kst["knn_ms"], "grow_kernel_ms": 0.0}, 1.0, args.rg_mode, "")
+            roof["scope"] = f"rank 0 of {world}: {n_knn} kNN queries, {n_grow} points grown"
             out = dict(common)
             out.update({"value": n * args.steps / elapsed / 1e6, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
                         "scaling": "strong",
                         "config": {"workload": args.workload, "points_total": n, "k": k, "rg_mode": args.rg_mode,
                                    "parallelism": f"stages 1-2: {world} Morton slabs, partition + halo by device all-to-all ({args.backend}); "
-                                                  "stage 3: replicas only (rank 0 grows, labels broadcast)",
+                                                  "stage 3: connected components of the kNN graph dealt to the ranks (union-find "
+                                                  "all-reduce MIN, one all-to-all per array), each rank grows whole components, "
+                                                  "plane ids from the all-gathered committed seeds, label all-reduce MAX",
                                    "halo_mm": info.get("halo"), "halo_retries": info.get("retries"),
-                                   "n_local_rank0": info.get("n_local")},
-                        "stages_ms": st,
+                                   "n_local_rank0": info.get("n_local"), "components": info.get("components"),
+                                   "cc_iterations": info.get("cc_iterations"), "points_grown_rank0": n_grow,
+                                   "points_grown_max_rank": n_grow_max, "planes": info.get("n_planes_total")},
+                        "stages_ms": st, "rank0_kernel_ms": kst,
                         "stage12_Mpoints_per_s": n / ((st["partition_ms"] + st["halo_ms"] + st["knn_normals_ms"]) * 1e-3) / 1e6,
-                        "roofline": None})
+                        "roofline": roof})
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.workload, xyz, k)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
