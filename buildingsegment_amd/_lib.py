@@ -23,7 +23,9 @@ EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "b
            "bs_segment_dev", "bs_planes_fetch", "bs_shift_to_origin_dev", "bs_plane_colors_dev",
            "bs_selftest_center_div", "bs_selftest_forge_next", "bs_set_audit", "bs_ingest_dev", "bs_grid_dims", "bs_grid_picture", "bs_grid_picture_dev",
            "bs_cc_hook_dev", "bs_owner_fetch_dev", "bs_labels_from_owner_dev", "bs_remap_rows_dev",
-           "bs_plane_seeds_dev", "bs_stream_sync"]
+           "bs_plane_seeds_dev", "bs_stream_sync", "bs_comm_rccl", "bs_comm_rccl_unique_id", "bs_comm_rccl_init",
+           "bs_comm_rccl_destroy", "bs_comm_local_create", "bs_comm_local_destroy", "bs_segment_sharded",
+           "bs_sharded_planes_fetch"]
 
 
 class Params(C.Structure):
@@ -45,6 +47,20 @@ class Timings(C.Structure):
                 ("grow_kernel_launches", C.c_int64), ("grow_setup_ms", C.c_double),
                 ("validation_rejects", C.c_int64), ("forged_seed", C.c_int64), ("forged_refused", C.c_int64),
                 ("audit_attempts", C.c_int64), ("audit_mismatches", C.c_int64), ("audit_ms", C.c_double)]
+
+
+class CommOps(C.Structure):
+    """bs_comm_ops (include/bs_api.h): the three collectives bs_segment_sharded is built on."""
+    _fields_ = [("handle", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32),
+                ("all_reduce", C.c_void_p), ("all_gather", C.c_void_p), ("all_to_all_v", C.c_void_p)]
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("n_own", C.c_int64), ("n_local", C.c_int64), ("n_grow", C.c_int64), ("components", C.c_int64),
+                ("planes_total", C.c_int64), ("cc_iterations", C.c_int32), ("halo_retries", C.c_int32),
+                ("halo_mm", C.c_double), ("ms_partition", C.c_double), ("ms_halo", C.c_double), ("ms_knn", C.c_double),
+                ("ms_components", C.c_double), ("ms_redistribute", C.c_double), ("ms_grow", C.c_double),
+                ("ms_labels", C.c_double)]
 
 
 class BsError(RuntimeError):
@@ -105,5 +121,15 @@ def load():
     L.bs_stream_sync.argtypes = [vp]
     L.bs_labels_from_owner_dev.argtypes = [vp, ip, C.c_int64, ip, C.c_int32, ip]
     L.bs_remap_rows_dev.argtypes = [vp, ip, C.c_int64, C.c_int32, ip, C.c_int64, ip, C.POINTER(C.c_int32)]
+    L.bs_comm_rccl.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(CommOps)]
+    L.bs_comm_rccl_unique_id.argtypes = [C.c_char_p]
+    L.bs_comm_rccl_init.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.bs_comm_rccl_destroy.argtypes = [vp]
+    L.bs_comm_local_create.argtypes = [C.c_int32, C.POINTER(CommOps)]
+    L.bs_comm_local_destroy.argtypes = [C.POINTER(CommOps)]
+    L.bs_comm_local_destroy.restype = None
+    L.bs_segment_sharded.argtypes = [vp, C.POINTER(CommOps), ip, ip, C.c_int64, C.c_int64, pp, C.c_double, ip,
+                                     C.POINTER(ShardInfo)]
+    L.bs_sharded_planes_fetch.argtypes = [vp, C.POINTER(Planes)]
     _LIB = L
     return L

@@ -254,6 +254,25 @@ class Context:
                                               C.byref(miss)))
         return miss.value
 
+    # ---- multi-GPU entry point of the C ABI (bs_segment_sharded) ----
+    def segment_sharded(self, comm_ops, d_xyz, d_gidx, m, n_total, d_plane_idx, params, halo=0.0) -> dict:
+        """ONE cloud spread over the ranks of `comm_ops` (a _lib.CommOps: bs_comm_rccl / bs_comm_local_create);
+        this rank passes its m points (device pointers).  d_plane_idx [n_total] receives the labels of the whole
+        cloud.  Returns bs_shard_info as a dict."""
+        inf = _lib.ShardInfo()
+        self._check(self._L.bs_segment_sharded(self._h, C.byref(comm_ops) if comm_ops is not None else None, d_xyz or None,
+                                               d_gidx or None, m, n_total, C.byref(params), float(halo), d_plane_idx,
+                                               C.byref(inf)))
+        return {k: getattr(inf, k) for k, _ in _lib.ShardInfo._fields_}
+
+    def sharded_planes_fetch(self):
+        """The planes THIS rank grew in the last segment_sharded, with global ids and global point indices."""
+        P = Planes()
+        self._check(self._L.bs_sharded_planes_fetch(self._h, C.byref(P)))
+        planes = _planes_to_list(P)
+        self._L.bs_planes_free(C.byref(P))
+        return planes
+
     def planes_fetch(self):
         P = Planes()
         self._check(self._L.bs_planes_fetch(self._h, C.byref(P)))

@@ -186,6 +186,8 @@ void bs_destroy(bs_ctx* c)
                         &c->rs_keys_in, &c->rs_keys_out, &c->rs_vals_in, &c->rs_vals_out, &c->rs_cnt, &c->rs_img, &c->rs_tmp};
   for (auto* b : bufs)
     b->release();
+  for (auto& b : c->sh)
+    b.release();
   c->rg_hout.release();
   for (auto& e : c->ev)
     if (e)

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/bs_api.h"
 
@@ -186,6 +187,11 @@ struct bs_ctx {
   // neighbour rows as cell-sorted POSITIONS (rows in position order), written by the kNN kernels of the fused
   // pipeline for the same cloud / k / neigh buffer: the grower takes them instead of translating indices
   bs::DevBuf seg_npos;
+  // scratch of the sharded pass (bs_sharded.hip): named by use there
+  bs::DevBuf sh[24];
+  std::vector<int32_t> sh_seeds;  // all committed seeds of the last bs_segment_sharded (global indices, ascending)
+  int64_t sh_nloc = 0;            // points this rank grew
+  bool sh_valid = false;
   const int32_t* npos_neigh = nullptr;
   const double* npos_normals = nullptr;
   int npos_k = 0;
@@ -206,6 +212,7 @@ int fail(bs_ctx* ctx, int status, const char* what, hipError_t e = hipSuccess);
 int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t n, double radius,
                int k, int cell_hint, GridDev* out);
 int build_spatial_order(bs_ctx* ctx, const int32_t* d_xyz, int64_t n);
+int bbox_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, int32_t bb[6]);
 // knn.hip
 int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q_end,
                        const bs_params& p, int32_t* d_neigh, double* d_normals, double cert_radius,

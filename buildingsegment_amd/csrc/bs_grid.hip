@@ -317,6 +317,21 @@ int build_grid(bs_ctx* ctx, const int32_t* d_xyz, const int32_t* d_gidx, int64_t
   return BS_OK;
 }
 
+// bounding box of a device-resident cloud (host result; synchronises): {min x,y,z, max x,y,z}
+int bbox_dev(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, int32_t bb[6])
+{
+  hipStream_t st = ctx->stream;
+  BS_HIP(ctx, ctx->misc.reserve(256));
+  int32_t init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
+  int32_t* d_mnmx = ctx->misc.as<int32_t>();
+  BS_HIP(ctx, hipMemcpyAsync(d_mnmx, init, sizeof init, hipMemcpyHostToDevice, st));
+  if (n > 0)
+    bbox_kernel<<<std::min(grid_blocks(n, 256), 512), 256, 0, st>>>(d_xyz, n, d_mnmx);
+  BS_HIP(ctx, hipMemcpyAsync(bb, d_mnmx, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  BS_HIP(ctx, hipStreamSynchronize(st));
+  return BS_OK;
+}
+
 // Spatial (Morton) order of a cloud WITHOUT a search grid: what the region grower needs when it is handed
 // foreign buffers (bs_region_grow[_dev], the component-sharded stage 3) -- its records, masks, reverse lists and
 // owner passes address points by their position in a spatially coherent order (bs_grow_spec.hip, "Index

@@ -483,7 +483,7 @@ def _grow_components(backend, own, neigh, normals, n_total, params, group, st, t
 
 
 def _iter_planes(pl):
-    """Plane records of either backend as dicts (api.Plane list, or the oracle's CSR dict)."""
+    """Plane records of either backend as dicts (an api.Plane list, or a CSR dict with id / normal / center / offset / point_idx)."""
     if pl is None:
         return
     if isinstance(pl, dict):

@@ -293,6 +293,69 @@ int bs_labels_from_owner_dev(bs_ctx* ctx, const int32_t* d_owner, int64_t n, con
 int bs_remap_rows_dev(bs_ctx* ctx, const int32_t* d_rows, int64_t n_rows, int32_t k, const int32_t* d_sorted_gidx,
                       int64_t n, int32_t* d_out, int32_t* n_missing);
 
+/* ---- multi-GPU entry point: ONE cloud sharded over the ranks of a communicator ----
+ *
+ * bs_segment_sharded is what the C++ host of TMC3.cpp:213-217 calls when it runs as one process per GPU: rank r
+ * passes the points it holds (any split of the cloud: d_xyz [m][3], d_gidx [m] = their global indices, both on
+ * its device) and receives planeIdx for the WHOLE cloud (d_plane_idx [n_total], device, identical on every rank).
+ * Stages 1-2 run on Morton slabs with a halo exchange, stage 3 on whole connected components of the kNN graph
+ * (see "building blocks" above); results equal the single-GPU / sequential ones bit for bit.
+ *
+ * The collectives are reached through bs_comm_ops: three operations on DEVICE buffers, enqueued on `stream`
+ * (the context's stream; they may synchronise it).  bs_comm_rccl() fills the table for an RCCL communicator
+ * (ncclComm_t; librccl.so.1 is resolved at run time) -- reductions by ncclAllReduce, gathers by ncclAllGather,
+ * the split-size all-to-all by grouped ncclSend / ncclRecv over xGMI.  A host with another transport (MPI, a test
+ * harness) supplies its own three functions.  Every function returns 0 or a non-zero error. */
+typedef enum bs_comm_dtype { BS_I32 = 0, BS_I64 = 1 } bs_comm_dtype;
+typedef enum bs_comm_op { BS_MIN = 0, BS_MAX = 1, BS_SUM = 2 } bs_comm_op;
+typedef struct bs_comm_ops {
+  void* handle; /* passed back as the first argument */
+  int32_t rank, world;
+  /* in-place all-reduce of count elements */
+  int (*all_reduce)(void* handle, void* d_buf, int64_t count, int dtype, int op, void* stream);
+  /* every rank contributes `bytes` bytes; d_recv receives world * bytes in rank order */
+  int (*all_gather)(void* handle, const void* d_send, void* d_recv, int64_t bytes, void* stream);
+  /* d_send holds the blocks for ranks 0..world-1 back to back (send_bytes[r] each, host array); d_recv receives the
+   * blocks of ranks 0..world-1 back to back (recv_bytes[r] each, host array, already agreed on by the caller) */
+  int (*all_to_all_v)(void* handle, const void* d_send, const int64_t* send_bytes, void* d_recv,
+                      const int64_t* recv_bytes, void* stream);
+} bs_comm_ops;
+
+/* RCCL-backed table for an existing communicator (`nccl_comm` is an ncclComm_t created by the host for this
+ * device).  BS_ERR_NO_DEVICE if librccl cannot be loaded. */
+int bs_comm_rccl(void* nccl_comm, int32_t rank, int32_t world, bs_comm_ops* out);
+/* Convenience for hosts without RCCL code of their own: rank 0 draws a 128-byte id and hands it to the other
+ * ranks by any means; every rank then creates its communicator for the context's device. */
+int bs_comm_rccl_unique_id(char id[128]);
+int bs_comm_rccl_init(bs_ctx* ctx, const char id[128], int32_t rank, int32_t world, void** nccl_comm);
+int bs_comm_rccl_destroy(void* nccl_comm);
+
+/* In-process communicator: the `world` ranks are THREADS of one process (one host thread per GPU without a
+ * launcher; several ranks sharing one GPU in the tests).  Fills out[0..world-1]; every rank's buffers must be
+ * reachable from the others' devices (same device, or peer access enabled by the host).  Collectives are device
+ * copies between the ranks' buffers behind a host barrier -- functional, not tuned: use bs_comm_rccl across GPUs. */
+int bs_comm_local_create(int32_t world, bs_comm_ops* out /* [world] */);
+void bs_comm_local_destroy(bs_comm_ops* ops /* one entry of the array; call for every rank */);
+
+typedef struct bs_shard_info {
+  int64_t n_own;        /* points of this rank's Morton slab */
+  int64_t n_local;      /* slab + halo */
+  int64_t n_grow;       /* points of the components this rank grew */
+  int64_t components;   /* connected components of the kNN graph (whole cloud) */
+  int64_t planes_total; /* committed planes (whole cloud) */
+  int32_t cc_iterations, halo_retries;
+  double halo_mm;
+  double ms_partition, ms_halo, ms_knn, ms_components, ms_redistribute, ms_grow, ms_labels; /* host wall time */
+} bs_shard_info;
+
+/* halo: initial halo width in mm (0 = 2 * radius); doubled until every k-list is certified.  d_gidx may be NULL
+ * only at world 1 (identity).  info is optional. */
+int bs_segment_sharded(bs_ctx* ctx, const bs_comm_ops* comm, const int32_t* d_xyz, const int32_t* d_gidx, int64_t m,
+                       int64_t n_total, const bs_params* p, double halo, int32_t* d_plane_idx, bs_shard_info* info);
+/* The planes THIS rank grew in the last bs_segment_sharded, with global ids (1-based rank of the seed among all
+ * committed seeds) and global point indices, ascending id.  Released by bs_planes_free. */
+int bs_sharded_planes_fetch(bs_ctx* ctx, bs_planes* planes);
+
 #ifdef __cplusplus
 }
 #endif
