@@ -169,8 +169,11 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
         (uint32_t)readlane_i32((int)(off & 0xffffffffu), 0);
   if (off + (unsigned long long)ncap > pool.cap)
     return false;
-  for (int32_t t = lane; t < used; t += 64)
-    pool.base[off + t] = ld_i32(pool.base + s.off + t);
+  for (int32_t t0 = 0; t0 < used; t0 += 64) {  // (uniform trip count: a per-lane loop exit makes the enclosing loops divergent)
+    const int32_t t = t0 + lane;
+    if (t < used)
+      pool.base[off + t] = ld_i32(pool.base + s.off + t);
+  }
   s.off = (int64_t)off;
   s.cap = (int32_t)ncap;
   return true;
@@ -1161,6 +1164,591 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
   }
 }
 
+// ---- step engine, second generation (BS_GROW_V2=0 selects the kernel above) -------------------------------------
+// Same protocol, same arithmetic, same results as grow_spec_kernel -- the step is re-cut around what the stamps of
+// the first engine showed (~3 000 cycles per step of ONE wave; identical at 19.6 k-, 90 k- and 250 k-point planes,
+// i.e. whether the records fit an XCD's L2 or not: the step is bound by the issue of the wave's own instruction
+// stream, not by where the gather is served from).  What changed:
+//  * HOT LOOP + COMPLETE STEP.  The loop that runs per step contains the common step only: pending calls in the LDS
+//    window, the first call with contenders claims without meeting an earlier plane, nothing to log, room in the LDS
+//    rings.  Everything else (refill, slow claim walk, assumption log, ring flushes, the depth-0 rule) is noticed
+//    BEFORE the step has a side effect and handled by ONE run of the complete step outside the loop.  With the rare
+//    paths inlined in the loop body the compiler kept its loop-carried scalars per lane in vector registers under
+//    exec-mask control flow (190-208 VGPRs, 57 spilled SGPRs); uniformity is also said explicitly (readfirstlane)
+//    where the divergence analysis gives up (merged exits behind per-lane branches, per-lane trip counts);
+//  * every vector-memory instruction of the hot loop is inline assembly behind ONE explicit wait: the claim tag rides
+//    in the same 16-byte sc1 load as the normal's third component, and no compiler-placed s_waitcnt vmcnt(0) sits
+//    right behind the previous step's claim atomics (600-900 cycles);
+//  * the LIFO lives in LDS only: its oldest 128 entries are flushed to the HBM slab in one coalesced burst when the
+//    256-entry window is full and come back the same way -- no write-through per push;
+//  * pointIdx entries are collected in an LDS ring and leave in coalesced bursts: no store, no address arithmetic
+//    and no slab-capacity check in the step;
+//  * distance and normal test are evaluated side by side (no short circuit).
+// Tried and measured slower (facade 1 M, growth kernels: this engine 136.6 ms, first engine 147.5 ms):
+//  * the candidates' neighbour rows fetched cooperatively (four lanes per row, 16 cache lines per instruction
+//    instead of 60, rows kept in that layout until the LDS push): 150-159 ms -- the four extra LIFO reads for the
+//    row duty and the issue of the re-addressed loads cost more than the saved line look-ups;
+//  * a single-exit loop (decide `commit` first, apply under one branch): 146.9 ms.
+constexpr int LBUF = 256;  // LDS ring of pointIdx entries (flushed in bursts of 64)
+#ifdef BS_PROBE
+// cycle stamps between the phases of a step (developer build: tools/probe_grow2.sh); planes with > 20 000 entries
+__device__ unsigned long long g_prof2[32];
+#define PROBE(i)                    \
+  do {                              \
+    const long long _t = clock64(); \
+    pacc[i] += _t - tlast;          \
+    tlast = _t;                     \
+  } while (0)
+#else
+#define PROBE(i) \
+  do {           \
+  } while (0)
+#endif
+
+typedef int v4i __attribute__((ext_vector_type(4)));  // a native 128-bit register tuple (inline-asm operand)
+
+template <int KC>
+__global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsigned long long* __restrict__ cand, int ncand,
+                                                        int4* rec, int32_t* dead, Pool pool,
+                                                        PlaneOut* __restrict__ out, int64_t step_cap, int retry_max_list,
+                                                        const uint32_t* __restrict__ order)
+{
+  __shared__ __attribute__((aligned(16))) int lds_stack[LDS_STACK * KC];
+  __shared__ int lbuf[LBUF];
+  constexpr int Q = RecLayout<KC>::QUADS;
+  constexpr int NG = 64 / KC;        // pending calls evaluated per step
+  constexpr int CH = KC / 4;         // 16-byte chunks of a neighbour row
+  if ((int)blockIdx.x >= ncand)
+    return;
+  const int w = order ? (int)(order[blockIdx.x] & (MAX_WAVES - 1)) : (int)blockIdx.x;
+  const int lane = threadIdx.x;
+  const int g = lane / KC, j = lane % KC;
+  const unsigned long long gmask0 = (KC == 32) ? 0xffffffffull : 0xffffull;
+  const int K = a.K, nc = K - 1;
+  const bool act = j < nc;
+  const int64_t t_start = (int64_t)wall_clock64();
+  const int32_t seed = (int32_t)(cand[w] >> 32);
+  const int32_t seed_s = (int32_t)(uint32_t)cand[w];
+  Slab list = {0, 0}, stack = {0, 0}, log = {0, 0};
+  int long_tries = 0;
+  int ln = 1, lflushed = 0, sp = 0, lds_lo = 0, logn = 0;
+  uint32_t iters = 0;
+  const uint32_t iter_cap = step_cap > 0xFFFFFFF0ll ? 0xFFFFFFF0u : (uint32_t)step_cap;
+  int status = ST_DONE;
+  bool pendv = false;
+  const int32_t* vptr = dead;
+  bool need_state = false;
+  const int4* srec = rec + (int64_t)seed_s * Q;
+  const int4 s0 = srec[0], s1 = srec[1], s2 = srec[2];
+  double cnx, cny, cnz, Sx, Sy, Sz;
+  int ccx, ccy, ccz;
+  uint32_t Cx, Cy, Cz;
+  unsigned long long d_am = 0;
+  double d_mx = 0, d_my = 0, d_mz = 0;
+  int d_px = 0, d_py = 0, d_pz = 0;
+  const bool have_mem = slab_ensure(pool, list, 0, 256, lane) && slab_ensure(pool, stack, 0, 32 * (int64_t)KC, lane) &&
+                        slab_ensure(pool, log, 0, 256, lane);
+  // pointIdx entries [lflushed, ln) are in the LDS ring; everything below is in the HBM slab
+  auto flush_list = [&](int upto) -> bool {  // make entries [lflushed, upto) durable (upto <= ln)
+    if (upto <= lflushed)
+      return true;
+    if (!slab_ensure(pool, list, lflushed, upto, lane))
+      return false;
+    for (int t0 = lflushed; t0 < upto; t0 += 64) {  // (uniform trip counts throughout: see slab_ensure)
+      const int t = t0 + lane;
+      if (t < upto)
+        pool.base[list.off + t] = lbuf[t & (LBUF - 1)];
+    }
+    lflushed = upto;
+    return true;
+  };
+  for (int attempt = 0;; attempt++) {
+    status = ST_DONE;
+    pendv = false;
+    ln = 1;
+    lflushed = 0;
+    sp = 0;
+    lds_lo = 0;
+    logn = 0;
+    cnx = __hiloint2double(s1.y, s1.x);
+    cny = __hiloint2double(s1.w, s1.z);
+    cnz = __hiloint2double(s2.y, s2.x);
+    ccx = s0.x;
+    ccy = s0.y;
+    ccz = s0.z;
+    Sx = 0.0 + cnx;
+    Sy = 0.0 + cny;
+    Sz = 0.0 + cnz;
+    Cx = (uint32_t)ccx;
+    Cy = (uint32_t)ccy;
+    Cz = (uint32_t)ccz;
+    need_state = false;
+    if (!have_mem) {
+      status = ST_NOMEM;
+    } else {
+      if (lane == 0)
+        lbuf[0] = seed_s;  // lists hold positions until they are committed
+      if (lane < KC)
+        lds_stack[lane] = reinterpret_cast<const int32_t*>(srec + 4)[lane];
+      sp = 1;
+      bool depth0 = true;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef BS_PROBE
+      long long pacc[12] = {0};
+      long long ncalls = 0, nexp = 0;
+      long long tlast = clock64();
+#endif
+      // ---- what every step starts with: pop, gather, plane state of the previous expansion, test, settle ----
+      // (straight-line code without exits: it is shared by the hot loop and by the complete step)
+      struct Ev {
+        int cand_id, px, py, pz, own, tg;
+        double mx, my, mz;
+        bool geo, valid;
+        int ngv;
+        bool lost_any;  // killed, or a claim of the previous call was lost
+        v4i rows[CH];  // the candidate's own neighbour row (it becomes its LIFO entry if it is accepted)
+      };
+      auto eval = [&](Ev& E) {
+        E.ngv = (sp < NG) ? sp : NG;
+        const int e = sp - 1 - g;
+        E.valid = e >= 0;
+        // unconditional LDS reads (the index is masked into the ring, the value is discarded where it means nothing):
+        // a read under `if` costs an exec-mask branch each, five of them in a row at the head of every step
+        {
+          const int v = lds_stack[(e & (LDS_STACK - 1)) * KC + ((j + 1) & (KC - 1))];
+          E.cand_id = (E.valid && act) ? v : 0;
+        }
+        // EVERY vector-memory instruction of the hot loop is issued from inline assembly and waited for by the ONE
+        // explicit s_waitcnt below.  Left to the compiler, the loop's first re-use of a load's destination register
+        // gets an s_waitcnt vmcnt(0) (the wait-count pass merges the back edge's pending events conservatively), and
+        // that wait sits right behind the previous step's claim atomics: 600-900 cycles per step.
+        // (the killed flag is read by every lane from ONE address, but the compiler cannot know that the lanes agree)
+        int killed_v, vt;
+        v4i q0, q1, q2;
+        {
+          const int32_t* kp = dead + seed;
+          const int32_t* vp = pendv ? vptr : dead + seed;
+          const int4* r = rec + (int64_t)E.cand_id * Q;
+          asm volatile("global_load_dword %3, %6, off sc1\n\t"
+                       "global_load_dword %4, %7, off sc1\n\t"
+                       "global_load_dwordx4 %0, %5, off\n\t"
+                       "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                       "global_load_dwordx4 %2, %5, off offset:32 sc1"
+                       : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(killed_v), "=&v"(vt)
+                       : "v"(r), "v"(kp), "v"(vp)
+                       : "memory");
+#pragma unroll
+          for (int t = 0; t < CH; t++) {
+            const int4* rp = r + 4 + t;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(E.rows[t]) : "v"(rp) : "memory");
+          }
+        }
+        PROBE(0);
+        // The plane state of the previous expansion is evaluated HERE, under the gather's latency.
+        if (__builtin_expect(need_state, 1)) {
+          unsigned long long mm = d_am;
+          while (mm) {
+            const int l = __ffsll(mm) - 1;
+            mm &= mm - 1;
+            Sx += readlane_f64(d_mx, l);
+            Sy += readlane_f64(d_my, l);
+            Sz += readlane_f64(d_mz, l);
+            Cx += (uint32_t)readlane_i32(d_px, l);
+            Cy += (uint32_t)readlane_i32(d_py, l);
+            Cz += (uint32_t)readlane_i32(d_pz, l);
+          }
+          const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+          cnx = Sx / nrm;
+          cny = Sy / nrm;
+          cnz = Sz / nrm;
+          const CenterDiv cd = center_div_prepare((uint32_t)ln);
+          ccx = center_div((int32_t)Cx, cd);
+          ccy = center_div((int32_t)Cy, cd);
+          ccz = center_div((int32_t)Cz, cd);
+          need_state = false;
+        }
+        PROBE(1);
+        // ---- the ONE wait of the gather (the operands tie every later use of the data behind it) ----
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(killed_v), "+v"(vt)::"memory");
+#pragma unroll
+        for (int t = 0; t < CH; t++)
+          asm volatile("" : "+v"(E.rows[t]));
+        PROBE(2);
+        E.px = q0.x;
+        E.py = q0.y;
+        E.pz = q0.z;
+        E.own = q0.w;
+        E.tg = q2.z;
+        E.mx = __hiloint2double(q1.y, q1.x);
+        E.my = __hiloint2double(q1.w, q1.z);
+        E.mz = __hiloint2double(q2.y, q2.x);
+        {
+          const int dx = (int)((uint32_t)E.px - (uint32_t)ccx);
+          const int dy = (int)((uint32_t)E.py - (uint32_t)ccy);
+          const int dz = (int)((uint32_t)E.pz - (uint32_t)ccz);
+          const double dist = __builtin_fabs((double)dx * cnx + (double)dy * cny + (double)dz * cnz);
+          const double dt = cnx * E.mx + cny * E.my + cnz * E.mz;
+          const bool okd = dist <= a.th, okn = dt >= a.cos_th;      // both chains run side by side
+          E.geo = E.valid & act & (E.tg != seed) & okd & okn;       // tg == seed: already labelled by this plane
+        }
+        const bool lost = pendv && vt != seed;  // an earlier plane got there first
+        E.lost_any = __builtin_amdgcn_readfirstlane(killed_v) != 0 || ballot64(lost) != 0;
+      };
+      // ---- expansion of call gstar (:231-255): list ring, deferred state, children onto the LIFO ----
+      auto expand = [&](const Ev& E, bool ok, unsigned long long am, int gstar, int cnt) {
+        const int rank = __popcll(am & ((1ull << lane) - 1ull));
+        if (ok)
+          lbuf[(ln + rank) & (LBUF - 1)] = E.cand_id;
+        d_am = am;
+        d_mx = E.mx;
+        d_my = E.my;
+        d_mz = E.mz;
+        d_px = E.px;
+        d_py = E.py;
+        d_pz = E.pz;
+        ln += cnt;
+        need_state = true;
+        PROBE(7);
+        // children onto the LIFO (reversed) with their rows; id in slot 0
+        if (ok) {
+          const int pe = sp + (cnt - 1 - rank);
+          v4i* lslot = reinterpret_cast<v4i*>(lds_stack + (pe & (LDS_STACK - 1)) * KC);
+#pragma unroll
+          for (int t = 0; t < CH; t++) {
+            v4i v = E.rows[t];
+            if (t == 0)
+              v.x = E.cand_id;
+            lslot[t] = v;
+          }
+        }
+        (void)gstar;
+        sp += cnt;
+      };
+      // ---- the COMPLETE step: every rare path (refill, slow claim walk, assumption log, ring flushes, depth 0) ----
+      // Returns 0 = step done, 2 = leave (status set or LIFO empty).  It is kept OUT of the hot loop's body: with the
+      // rare paths inlined there the loop-carried scalars were spilled or kept per lane (57 spilled SGPRs, 190-208 VGPRs).
+      auto step_complete = [&]() -> int {
+        if (__builtin_expect(sp == 0, 0))
+          return 2;
+        if (__builtin_expect(++iters > iter_cap, 0)) {
+          status = ST_WATCHDOG;
+          return 2;
+        }
+        const int need_lo = (sp - NG > 0) ? sp - NG : 0;
+        if (__builtin_expect(need_lo < lds_lo, 0)) {  // the pops reach below the LDS window: bring LDS_REFILL entries back
+          const int new_lo = lds_lo > LDS_REFILL ? lds_lo - LDS_REFILL : 0;
+          const int nw = (lds_lo - new_lo) * KC;
+          for (int t0 = 0; t0 < nw; t0 += 64) {
+            const int t = t0 + lane;
+            const int ee = new_lo + t / KC;
+            if (t < nw)
+              lds_stack[(ee & (LDS_STACK - 1)) * KC + (t % KC)] = ld_i32(pool.base + stack.off + (int64_t)new_lo * KC + t);
+          }
+          lds_lo = new_lo;
+        }
+        Ev E;
+        eval(E);
+        pendv = false;
+        if (__builtin_expect(E.lost_any, 0)) {
+          status = ST_STOLEN;
+          return 2;
+        }
+        bool assume = E.geo && E.own < seed && !(E.own < a.F);
+        const bool contender = E.geo && !(E.own < seed);
+        const unsigned long long cm = ballot64(contender);
+        unsigned long long am = 0;
+        int gstar = -1;
+        bool ok = false;
+        const int cand_id = E.cand_id, tg = E.tg, ngv = E.ngv;
+        if (cm != 0) {
+          const int g1 = (__ffsll(cm) - 1) / KC;
+          const unsigned long long gm1 = gmask0 << (g1 * KC);
+          const unsigned long long earlier = ballot64(contender && tg < seed);
+          if ((earlier & gm1) == 0) {
+            ok = contender && g == g1;
+            if (ok) {
+              int32_t* tp = rec_tag(rec, Q, cand_id);
+              __hip_atomic_fetch_min(tp, seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // no-return form
+              if (tg != INF)
+                __hip_atomic_store(dead + tg, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              vptr = tp;
+              pendv = true;
+            }
+            am = cm & gm1;
+            gstar = g1;
+          } else {
+            for (int gg = g1; gg < ngv; gg++) {
+              const unsigned long long gm = gmask0 << (gg * KC);
+              if (cm & gm) {
+                if (g == gg && contender) {
+                  int32_t* tp = rec_tag(rec, Q, cand_id);
+                  int cur_tag = tg;
+                  bool mine = false;
+                  for (int tries = 0; tries < 8 && !ok && !assume && !mine; tries++) {
+                    if (cur_tag < seed) {
+                      if (ld_i32(dead + cur_tag) < 0) {
+                        const int old = atomicCAS(tp, cur_tag, seed);
+                        if (old == cur_tag)
+                          ok = true;
+                        else
+                          cur_tag = old;
+                      } else {
+                        assume = true;
+                      }
+                    } else if (cur_tag == seed) {
+                      mine = true;
+                    } else {
+                      const int old = atomicMin(tp, seed);
+                      if (old > seed) {
+                        if (old != INF)
+                          __hip_atomic_store(dead + old, seed + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = true;
+                      } else if (old == seed) {
+                        mine = true;
+                      } else {
+                        cur_tag = old;
+                      }
+                    }
+                  }
+                  if (!ok && !mine)
+                    assume = true;
+                }
+                am = ballot64(ok);
+                if (am) {
+                  gstar = gg;
+                  break;
+                }
+              }
+            }
+          }
+        }
+        const int last = gstar >= 0 ? gstar : ngv - 1;
+        const unsigned long long lm = ballot64(assume && g <= last);
+        if (lm != 0) {
+          const int lcnt = __popcll(lm);
+          if (!slab_ensure(pool, log, logn, logn + lcnt, lane)) {
+            status = ST_NOMEM;
+            return 2;
+          }
+          if (assume && g <= last)
+            pool.base[log.off + logn + __popcll(lm & ((1ull << lane) - 1ull))] = cand_id;
+          logn += lcnt;
+        }
+        const int cnt = __popcll(am);
+        if (depth0 && cnt < nc) {
+          status = ST_FAILED0;
+          return 2;
+        }
+        depth0 = false;
+        sp -= last + 1;
+        if (gstar < 0)
+          return 0;
+        if (ln + cnt - lflushed > LBUF) {  // the ring is full: a coalesced burst to the HBM slab
+          if (!flush_list(ln)) {
+            status = ST_NOMEM;
+            return 2;
+          }
+        }
+        if (sp + cnt - lds_lo > LDS_STACK) {  // LIFO window full: its oldest half goes to HBM
+          const int upto = lds_lo + LDS_STACK / 2;
+          if (!slab_ensure(pool, stack, lds_lo > 0x7ffffff0 / KC ? 0x7ffffff0 : lds_lo * KC, (int64_t)upto * KC, lane)) {
+            status = ST_NOMEM;
+            return 2;
+          }
+          for (int t0 = 0; t0 < (LDS_STACK / 2) * KC; t0 += 64) {
+            const int t = t0 + lane;
+            const int ee = lds_lo + t / KC;
+            pool.base[stack.off + (int64_t)lds_lo * KC + t] = lds_stack[(ee & (LDS_STACK - 1)) * KC + (t % KC)];
+          }
+          lds_lo = upto;
+        }
+        expand(E, ok, am, gstar, cnt);
+        return 0;
+      };
+      // (what a complete step leaves behind is wave-uniform; said explicitly, because its exits merge behind per-lane
+      // branches and the divergence analysis gives up on them -- and then on every scalar of the hot loop)
+      auto uniform_state = [&]() {
+        sp = __builtin_amdgcn_readfirstlane(sp);
+        ln = __builtin_amdgcn_readfirstlane(ln);
+        lds_lo = __builtin_amdgcn_readfirstlane(lds_lo);
+        lflushed = __builtin_amdgcn_readfirstlane(lflushed);
+        logn = __builtin_amdgcn_readfirstlane(logn);
+        iters = (uint32_t)__builtin_amdgcn_readfirstlane((int)iters);
+        status = __builtin_amdgcn_readfirstlane(status);
+        d_am = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(d_am >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)d_am);
+      };
+      // ---- driver: a complete step (the first one is the depth-0 step), then the hot loop until a step is not its kind ----
+      for (;;) {
+        const int r = __builtin_amdgcn_readfirstlane(step_complete());
+        uniform_state();
+        if (r == 2)
+          break;
+        bool leave = false;
+        // (nothing may be in flight when the hot loop is entered: a load still pending at its preheader makes the
+        // wait-count pass put an s_waitcnt vmcnt(0) at the loop's first register re-use -- executed in EVERY iteration,
+        // where it waits for the previous step's claim atomics, 600-900 cycles)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // ---- the HOT LOOP: the common step only, every exit is a wave-uniform break BEFORE the step has a side effect ----
+        for (;;) {
+          if (__builtin_expect(sp == 0, 0)) {
+            leave = true;
+            break;
+          }
+          PROBE(9);
+#ifdef BS_PROBE
+          ncalls++;
+#endif
+          if (__builtin_expect(iters >= iter_cap, 0))
+            break;  // (the complete step raises the watchdog)
+          if (__builtin_expect(((sp - NG > 0) ? sp - NG : 0) < lds_lo, 0))
+            break;  // refill
+          Ev E;
+          eval(E);
+          if (__builtin_expect(E.lost_any, 0)) {
+            pendv = false;
+            status = ST_STOLEN;
+            leave = true;
+            break;
+          }
+          const bool assume = E.geo && E.own < seed && !(E.own < a.F);
+          const bool contender = E.geo && !(E.own < seed);
+          const unsigned long long cm = ballot64(contender);
+          PROBE(3);
+          int gstar = -1, cnt = 0;
+          unsigned long long am = 0;
+          if (__builtin_expect(cm != 0, 1)) {
+            gstar = (__ffsll(cm) - 1) / KC;
+            const unsigned long long gm1 = gmask0 << (gstar * KC);
+            am = cm & gm1;
+            cnt = __popcll(am);
+            // everything this loop cannot do is known here, before the first claim is issued
+            const bool slow = (ballot64(contender && E.tg < seed) & gm1) != 0 || ballot64(assume && g <= gstar) != 0 ||
+                              ln + cnt - lflushed > LBUF || sp - (gstar + 1) + cnt - lds_lo > LDS_STACK;
+            if (__builtin_expect(slow, 0))
+              break;
+          } else if (__builtin_expect(ballot64(assume) != 0, 0)) {
+            break;  // only empty calls, but one of them assumed something: the complete step logs it
+          }
+          // ---- committed: from here on the step has side effects ----
+          iters++;
+          pendv = false;
+          const bool ok = contender && g == gstar;
+          if (ok) {
+            int32_t* tp = rec_tag(rec, Q, E.cand_id);
+            // no-return atomicMin (agent scope) on the tag; a later holder (tag > seed here) is invalid now
+            asm volatile("global_atomic_smin %0, %1, off" ::"v"(tp), "v"(seed) : "memory");
+            if (E.tg != INF) {
+              int32_t* dp = dead + E.tg;
+              const int thief = seed + 1;
+              asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dp), "v"(thief) : "memory");
+            }
+            vptr = tp;
+            pendv = true;
+          }
+          PROBE(4);
+          sp -= (gstar >= 0 ? gstar : E.ngv - 1) + 1;
+          PROBE(5);
+          if (gstar >= 0) {
+#ifdef BS_PROBE
+            nexp++;
+#endif
+            PROBE(6);
+            expand(E, ok, am, gstar, cnt);
+            PROBE(8);
+          }
+        }
+        if (leave)
+          break;
+      }
+#ifdef BS_PROBE
+      if (lane == 0 && ln > 20000) {
+        for (int i = 0; i < 10; i++)
+          atomicAdd(&g_prof2[i], (unsigned long long)pacc[i]);
+        atomicAdd(&g_prof2[10], (unsigned long long)ncalls);
+        atomicAdd(&g_prof2[11], (unsigned long long)nexp);
+      }
+#endif
+    }
+    if (need_state) {  // state of the very last expansion (the plane's reported normal / centre)
+      unsigned long long mm = d_am;
+      while (mm) {
+        const int l = __ffsll(mm) - 1;
+        mm &= mm - 1;
+        Sx += readlane_f64(d_mx, l);
+        Sy += readlane_f64(d_my, l);
+        Sz += readlane_f64(d_mz, l);
+        Cx += (uint32_t)readlane_i32(d_px, l);
+        Cy += (uint32_t)readlane_i32(d_py, l);
+        Cz += (uint32_t)readlane_i32(d_pz, l);
+      }
+      const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+      cnx = Sx / nrm;
+      cny = Sy / nrm;
+      cnz = Sz / nrm;
+      const CenterDiv cd = center_div_prepare((uint32_t)ln);
+      ccx = center_div((int32_t)Cx, cd);
+      ccy = center_div((int32_t)Cy, cd);
+      ccz = center_div((int32_t)Cz, cd);
+      need_state = false;
+    }
+    if (have_mem && status != ST_NOMEM && !flush_list(ln))  // the whole list is in the HBM slab from here on
+      status = ST_NOMEM;
+    if (status == ST_DONE) {
+      const bool lost = pendv && ld_i32(vptr) != seed;
+      if (ballot64(lost))
+        status = ST_STOLEN;
+    }
+    bool seed_taken = false;
+    if (status == ST_STOLEN) {  // (uniform loads, said explicitly: a divergent exit of the attempt loop costs the whole kernel its scalars)
+      const int t0 = __builtin_amdgcn_readfirstlane(ld_i32(rec_tag(rec, Q, seed_s)));
+      seed_taken = t0 < seed && __builtin_amdgcn_readfirstlane(ld_i32(dead + (t0 < seed ? t0 : seed))) >= 0;
+    }
+    if (status != ST_STOLEN || seed_taken || attempt >= MAX_RETRY || ln > retry_max_list ||
+        (ln > RETRY_MAX_LIST && ++long_tries > MAX_RETRY_LONG))
+      break;
+    for (int t0 = 1; t0 < ln; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < ln)
+        atomicCAS(rec_tag(rec, Q, ld_i32(pool.base + list.off + t)), seed, INF);
+    }
+    __hip_atomic_store(dead + seed, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }  // attempt loop
+  if (lane == 0 && status == ST_STOLEN) {
+    const int t = ld_i32(dead + seed);
+    __hip_atomic_store(dead + seed, t > 0 ? -t : (t == 0 ? -0x40000000 : t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (lane == 0) {
+    PlaneOut o;
+    o.normal[0] = cnx;
+    o.normal[1] = cny;
+    o.normal[2] = cnz;
+    o.center[0] = ccx;
+    o.center[1] = ccy;
+    o.center[2] = ccz;
+    o.list_off = list.off;
+    o.list_n = ln;
+    o.log_off = log.off;
+    o.log_n = logn;
+    o.steps = iters;
+    o.seed = seed;
+    o.status = status;
+    o.keep = (status == ST_DONE && ln > a.th_count) ? 1 : 0;
+    o.consistent = 0;
+    o.pad = 0;
+    const int dflag = ld_i32(dead + seed);
+    o.thief = (dflag < 0 ? -dflag : dflag) - 1;
+    o.seed_pos = seed_s;
+    o.v3ok = 1;
+    o.pad4 = 0;
+    o.t_start = t_start;
+    o.t_end = (int64_t)wall_clock64();
+    o.w = w;
+    o.pad5 = 0;
+    out[w] = o;
+  }
+}
+
 // The per-plane list kernels run one BLOCK of VT threads per plane: a 100 k-point
 // list walked by a single wave is 1700 dependent gathers per lane (0.7 ms).
 constexpr int VT = 1024;
@@ -1925,6 +2513,8 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   const int lds_pad = getenv("BS_GROW_LDS_PAD") ? atoi(getenv("BS_GROW_LDS_PAD")) : 0;  // experiment: unused dynamic LDS lowers the occupancy
   const bool dbg = getenv("BS_DEBUG") != nullptr;  // (not once per attempt: 158 k of them in a first round)
   const bool do_validate3 = getenv("BS_NO_VALIDATE3") == nullptr;  // developer A/B switch
+  // Step engine: grow_spec2_kernel (hot loop + complete step); BS_GROW_V2=0 selects the first-generation kernel (A/B).
+  const bool grow_v1 = getenv("BS_GROW_V2") != nullptr && atoi(getenv("BS_GROW_V2")) == 0;
   BS_HIP(ctx, hipMemsetAsync(d_misc + 4, 0, 3 * sizeof(int), st));  // [4] refused planes, [5] forged seed + 1, [6] forged one refused
   for (;;) {
     rounds++;
@@ -1996,10 +2586,17 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       // is grown again has the time to finish inside the same launch (urban 10 M: +20 %); in a round of a few
       // chained planes (the facade) the re-growth only repeats work the next round does anyway (-23 %).
       const int rml = (ncand >= retry_big_round && !retry_env) ? 0x7fffffff : retry_max_list;
-      if (KC == 16)
-        grow_spec_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
-      else
-        grow_spec_kernel<32><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
+      if (grow_v1) {
+        if (KC == 16)
+          grow_spec_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
+        else
+          grow_spec_kernel<32><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
+      } else {
+        if (KC == 16)
+          grow_spec2_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
+        else
+          grow_spec2_kernel<32><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
+      }
       (void)hipEventRecord(ctx->ev[7], st);
       grow_launches++;
       timed_round = true;
@@ -2097,6 +2694,17 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         return fail(ctx, BS_ERR_NOMEM, "region grow (speculative): round pool exhausted");
       max_waves = std::max(1, max_waves / 8);
     }
+#ifdef BS_PROBE
+    if (dbg) {
+      unsigned long long hp[32];
+      (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof2), sizeof(hp));
+      const double nstep = (double)hp[10] + 1.0;
+      fprintf(stderr, "[prof2] steps=%llu expansions=%llu | pop+issue=%.0f state=%.0f wait=%.0f test+classify=%.0f claims+walk=%.0f log+counters=%.0f "
+                      "flushchk=%.0f list+defer=%.0f push=%.0f top=%.0f (cycles per step, cumulative over rounds)\n",
+              hp[10], hp[11], hp[0] / nstep, hp[1] / nstep, hp[2] / nstep, hp[3] / nstep, hp[4] / nstep, hp[5] / nstep, hp[6] / nstep,
+              hp[7] / nstep, hp[8] / nstep, hp[9] / nstep);
+    }
+#endif
     if (dbg) {
       int cnt[6] = {0, 0, 0, 0, 0, 0}, cons = 0, pcons = 0;
       int64_t maxsteps = 0, sumsteps = 0, maxlist = 0;
@@ -2327,10 +2935,17 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       BS_HIP(ctx, hipMemcpyAsync(d_cand, hc_sorted.data(), sizeof(unsigned long long) * na, hipMemcpyHostToDevice, st));
     a.F = INF;
     auto grow_n = [&](int off, int cnt, PlaneOut* o) {
-      if (KC == 16)
-        grow_spec_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
-      else
-        grow_spec_kernel<32><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
+      if (grow_v1) {
+        if (KC == 16)
+          grow_spec_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
+        else
+          grow_spec_kernel<32><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
+      } else {
+        if (KC == 16)
+          grow_spec2_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
+        else
+          grow_spec2_kernel<32><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
+      }
     };
     auto compare_n = [&](int cnt) {
       audit_compare_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, prio, d_seeds, ctx->rg_planes.as<PlaneRec>(), np,
