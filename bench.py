@@ -39,9 +39,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-WORKLOADS = ["urban_50m", "urban_10m", "facade_1m", "plane_cube_100k", "uniform_1m", "urban_2m", "urban_200m"]
+WORKLOADS = ["urban_50m", "urban_10m", "facade_1m", "plane_cube_100k", "uniform_1m", "uniform_10m", "urban_2m", "urban_200m"]
 K_DEFAULT = {"facade_1m": 16, "urban_10m": 32, "urban_50m": 16, "urban_2m": 16, "plane_cube_100k": 15,
-             "uniform_1m": 16, "urban_200m": 16}
+             "uniform_1m": 16, "uniform_10m": 16, "urban_200m": 16}
 
 
 def parse():
@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path "
                          "with several ranks sharing one GPU)")
-    ap.add_argument("--secondary", default="facade_1m,urban_10m",
+    ap.add_argument("--secondary", default="facade_1m,urban_10m,uniform_1m,uniform_10m",
                     help="comma-separated workloads measured live after the headline and reported under "
                          "'secondary' ('' = none; ignored for N>1)")
     ap.add_argument("--concurrent", type=int, default=2,
@@ -98,6 +98,8 @@ def make_cloud(name: str, rank: int = 0):
         return synth.plane_cube(seed=1), 15
     if name == "uniform_1m":
         return synth.uniform(1_000_000, seed=6), 16
+    if name == "uniform_10m":
+        return synth.uniform(10_000_000, seed=6), 16
     raise ValueError(name)
 
 
@@ -112,21 +114,25 @@ def cpu_model() -> str:
 
 
 def cpu_baseline(name: str, xyz: np.ndarray, k: int):
-    """CPU oracle (oracle/bs_oracle.c, ONE thread) on a bounded sample of the same workload.
+    """CPU oracle (oracle/bs_oracle.c, ONE thread) on a bounded sample of the same workload, with the per-stage split.
 
     Small workloads run whole.  The urban clouds are generated building by building from
     counter-based streams, so `synth.urban(m, seed)` IS the first m points (the first
     buildings) of the larger cloud of the same seed: that sub-scene is segmented end to end
-    (kNN + normals + region grow) -- the same density, plane sizes and k as the full job."""
+    (kNN + normals + region grow) -- the same density, plane sizes and k as the full job.
+    The uniform control cloud has one density at every size (mean spacing 50 mm): its 1 M instance stands for 10 M."""
     from buildingsegment_amd import synth
     from oracle import oracle as O
     n = len(xyz)
-    sample_n = {"urban_50m": 2_000_000, "urban_200m": 2_000_000, "urban_10m": 1_000_000}.get(name, n)
-    if sample_n < n:
+    sample_n = {"urban_50m": 2_000_000, "urban_200m": 2_000_000, "urban_10m": 1_000_000, "uniform_10m": 1_000_000}.get(name, n)
+    if sample_n < n and name.startswith("urban"):
         seed = {"urban_50m": 4, "urban_200m": 5, "urban_10m": 3}[name]
         sub = synth.urban(sample_n, seed=seed)
         what = (f"synth.urban({sample_n}, seed={seed}) = the first {sample_n} points (first buildings) of the {name} "
                 "generator stream, whole path")
+    elif sample_n < n:
+        sub = synth.uniform(sample_n, seed=6)
+        what = f"synth.uniform({sample_n}, seed=6): the same density (mean spacing 50 mm) as {name}, whole path"
     else:
         sub = xyz
         what = f"whole workload ({n} points)"
@@ -135,8 +141,11 @@ def cpu_baseline(name: str, xyz: np.ndarray, k: int):
     t1 = time.perf_counter()
     O.region_grow(sub, normals, neigh)
     t2 = time.perf_counter()
-    return {"value": len(sub) / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
+    m = len(sub)
+    return {"value": m / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
             "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+            "stages_s": {"knn_normals": t1 - t0, "region_grow": t2 - t1},
+            "stage_Mpoints_per_s": {"knn_normals": m / (t1 - t0) / 1e6, "region_grow": m / max(t2 - t1, 1e-9) / 1e6},
             "sample": f"{what}: kNN+normals {t1 - t0:.2f}s, region grow {t2 - t1:.2f}s on 1 thread"}
 
 
@@ -227,6 +236,10 @@ def measure_single(ctx, api, torch, dev, name, k_override, rg_mode, steps, warmu
            "stages_ms": stage, "rg_rounds": tm["rg_rounds"], "largest_plane": tm["largest_plane"],
            "seed_attempts": tm["n_seed_attempts"], "fallback_queries": tm["n_fallback_queries"],
            "validation_rejects": tm["validation_rejects"],
+           "validation_rejects_by_check": {"robbed_after_finish": tm["rej_v1_robbed"], "entry_without_claim": tm["rej_v1_tag"],
+                                           "duplicate_entry": tm["rej_v1_dup"], "state_not_reproducible": tm["rej_v3_state"]},
+           "inconsistent_by_test": {"seed_row": tm["incons_seed"], "list": tm["incons_list"], "assumption_log": tm["incons_log"]},
+           "tie_rows": tm["tie_rows"], "tie_rows_frac": tm["tie_rows"] / max(n, 1),
            "end_to_end_alg_GBps": n * (88 + 8 * k) / (elapsed / max(steps, 1)) / 1e9,
            "roofline": roofline_block(n, k, stage, launches / max(steps, 1), rg_mode, name),
            "radius_mm": params.radius, "max_nn": params.max_nn}
@@ -363,6 +376,8 @@ def main():
                                    "largest_plane": res["largest_plane"], "seed_attempts": res["seed_attempts"],
                                    "fallback_queries": res["fallback_queries"], "rg_rounds": res["rg_rounds"],
                                    "validation_rejects": res["validation_rejects"],
+                                   "validation_rejects_by_check": res["validation_rejects_by_check"],
+                                   "tie_rows": res["tie_rows"], "tie_rows_frac": res["tie_rows_frac"],
                                    "parallelism": "1 GPU, whole path" if world == 1 else f"{world} independent replicas"},
                         "stages_ms": res["stages_ms"], "end_to_end_alg_GBps": res["end_to_end_alg_GBps"],
                         "roofline": res["roofline"]})
@@ -374,10 +389,13 @@ def main():
         if world == 1 and args.secondary:
             sec = []
             for name in [s for s in args.secondary.split(",") if s and s != args.workload]:
-                r2, _, _ = measure_single(ctx, api, torch, dev, name, 0, args.rg_mode, 2, 1, fence,
-                                          audit=(not args.no_audit and args.rg_mode in (0, 2)))
+                r2, xyz2, k2 = measure_single(ctx, api, torch, dev, name, 0, args.rg_mode, 2, 1, fence,
+                                              audit=(not args.no_audit and args.rg_mode in (0, 2)))
                 for drop in ("radius_mm", "max_nn"):
                     r2.pop(drop)
+                if not args.no_cpu_baseline:  # each secondary beside ITS OWN one-thread CPU oracle run (per-stage split)
+                    r2["cpu_baseline"] = cpu_baseline(name, xyz2, k2)
+                del xyz2
                 sec.append(r2)
             if rank == 0 and sec:
                 out["secondary"] = sec

@@ -17,7 +17,7 @@ STATUS = {0: "BS_OK", -1: "BS_ERR_INVALID", -2: "BS_ERR_RANGE", -3: "BS_ERR_NOME
           -5: "BS_ERR_NO_DEVICE", -6: "BS_ERR_INTERNAL", -7: "BS_ERR_UNCERTIFIED"}
 
 # every symbol include/bs_api.h declares
-EXPORTS = ["bs_api_version", "bs_strerror", "bs_params_default", "bs_create", "bs_destroy", "bs_last_error",
+EXPORTS = ["bs_api_version", "bs_sizeof_timings", "bs_strerror", "bs_params_default", "bs_create", "bs_destroy", "bs_last_error",
            "bs_set_stream", "bs_get_timings", "bs_knn_normals", "bs_knn_normals_halo", "bs_region_grow", "bs_segment",
            "bs_planes_free", "bs_plane_colors", "bs_knn_normals_dev", "bs_region_grow_dev",
            "bs_segment_dev", "bs_planes_fetch", "bs_shift_to_origin_dev", "bs_plane_colors_dev",
@@ -46,7 +46,12 @@ class Timings(C.Structure):
                 ("n_fallback_queries", C.c_int64), ("rg_rounds", C.c_int64), ("grow_kernel_ms", C.c_double),
                 ("grow_kernel_launches", C.c_int64), ("grow_setup_ms", C.c_double),
                 ("validation_rejects", C.c_int64), ("forged_seed", C.c_int64), ("forged_refused", C.c_int64),
-                ("audit_attempts", C.c_int64), ("audit_mismatches", C.c_int64), ("audit_ms", C.c_double)]
+                ("audit_attempts", C.c_int64), ("audit_mismatches", C.c_int64), ("audit_ms", C.c_double),
+                ("tie_rows", C.c_int64), ("rej_v1_robbed", C.c_int64), ("rej_v1_tag", C.c_int64), ("rej_v1_dup", C.c_int64),
+                ("rej_v3_state", C.c_int64), ("incons_seed", C.c_int64), ("incons_list", C.c_int64),
+                ("incons_log", C.c_int64)]
+
+API_VERSION = 5  # BS_API_VERSION of include/bs_api.h this loader mirrors
 
 
 class CommOps(C.Structure):
@@ -81,6 +86,11 @@ def load():
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m buildingsegment_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     L = C.CDLL(LIB_PATH)
+    L.bs_api_version.restype = C.c_int
+    L.bs_sizeof_timings.restype = C.c_int64
+    if L.bs_api_version() != API_VERSION or L.bs_sizeof_timings() != C.sizeof(Timings):
+        raise ImportError(f"{LIB_PATH} is API version {L.bs_api_version()} (bs_timings: {L.bs_sizeof_timings()} bytes), this "
+                          f"loader mirrors version {API_VERSION} ({C.sizeof(Timings)} bytes): rebuild the library")
     vp, ip, dp, lp = C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
     pp = C.POINTER(Params)
     L.bs_api_version.restype = C.c_int

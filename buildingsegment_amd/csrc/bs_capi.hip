@@ -113,6 +113,8 @@ extern "C" {
 
 int bs_api_version(void) { return BS_API_VERSION; }
 
+int64_t bs_sizeof_timings(void) { return (int64_t)sizeof(bs_timings); }
+
 const char* bs_strerror(int status)
 {
   switch (status) {

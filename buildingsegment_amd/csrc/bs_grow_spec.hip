@@ -1763,7 +1763,8 @@ __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand,
     return;
   const PlaneOut o = out[w];
   // lost a point after it had finished, or an impossible list (each point at most once + the seed)
-  bool bad = dead[o.seed] != 0 || o.list_n > n + 1;
+  const bool robbed = dead[o.seed] != 0 || o.list_n > n + 1;
+  bool bad = robbed, bad_tag = false, bad_dup = false;
   // ... and no point may be listed twice (the claim protocol inside the launch is advisory; a plane that
   // reclaimed a point it already held would pass the tag test).  vmark[p] receives a key that is unique
   // per (round, plane): meeting one's own key again is a duplicate.  The seed's second appearance (quirk
@@ -1771,15 +1772,22 @@ __global__ __launch_bounds__(VT) void validate1_kernel(PlaneOut* out, int ncand,
   const int32_t key = round_key + w + 1;
   for (int64_t t = 1 + threadIdx.x; t < o.list_n; t += VT) {
     const int32_t p = pool[o.list_off + t];
-    bad = bad || *rec_tag(rec, quads, p) != o.seed;
+    const bool tagbad = *rec_tag(rec, quads, p) != o.seed;
+    bad_tag = bad_tag || tagbad;
     const bool dup = atomicExch(&vmark[p], key) == key;
     if (dup)
       atomicAdd(rejects, 1);
-    bad = bad || dup;
+    bad_dup = bad_dup || dup;
+    bad = bad || tagbad || dup;
   }
   const int b = __syncthreads_or(bad);  // (also orders the reads of out[w] above before the write below)
+  const int bt = __syncthreads_or(bad_tag), bd = __syncthreads_or(bad_dup);
   if (threadIdx.x == 0) {
     if (b) {
+      // which check refused the plane (bs_timings.rej_v1_*): [8] robbed after it finished, [9] a list entry without the
+      // plane's claim, [10] a point listed twice
+      atomicAdd(rejects + (robbed ? 8 : (bd ? 10 : 9)), 1);
+      (void)bt;
       out[w].status = ST_STOLEN;
       if (rejects[1] == o.seed + 1)
         rejects[2] = 1;  // the plane the self-test forged was refused
@@ -1931,6 +1939,7 @@ __global__ __launch_bounds__(V3T) void validate3_kernel(PlaneOut* out, int ncand
     if (!same) {
       out[w].v3ok = 0;  // the host treats the plane as inconsistent: dropped from the structure, grown again
       atomicAdd(rejects, 1);
+      atomicAdd(rejects + 11, 1);  // bs_timings.rej_v3_state
       if (rejects[1] == o.seed + 1)
         rejects[2] = 1;
     }
@@ -2071,12 +2080,23 @@ __global__ __launch_bounds__(VT) void validate2_kernel(PlaneOut* out, int ncand,
 __global__ __launch_bounds__(VT) void audit_compare_kernel(const PlaneOut* __restrict__ out, int na,
                                                            const int32_t* __restrict__ pool, const int32_t* __restrict__ prio,
                                                            const int32_t* __restrict__ seeds, const PlaneRec* __restrict__ planes,
-                                                           int np, const int32_t* __restrict__ lists, int64_t th_count, int* stats)
+                                                           int np, const int32_t* __restrict__ lists, int64_t th_count, int* stats,
+                                                           const int32_t* __restrict__ dead, int32_t* __restrict__ retry)
 {
   const int w = blockIdx.x;
   if (w >= na)
     return;
   const PlaneOut o = out[w];
+  if (retry) {
+    // batched replay of attempts the reference rolls back: they may meet each other.  Whoever was robbed, or treated a
+    // point as held by another attempt of the batch (logged), did NOT see the sequential state: it is replayed again
+    // in the next batch instead of being judged (the lowest seed of a batch is never interfered with).
+    const bool interfered = o.status != ST_DONE || o.log_n != 0 || dead[o.seed] != 0;
+    if (threadIdx.x == 0)
+      retry[w] = interfered ? 1 : 0;
+    if (interfered)
+      return;
+  }
   int lo = 0, hi = np;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -2411,8 +2431,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // nothing dirty costs microseconds, a round trip ~50 us, and a plane insertion settles in 8-25 passes.
   // Every pass reports its flips in its own word; the structure is a fixed point when the LAST pass of a
   // group flipped nothing (the passes after the settling one find no dirty point and do nothing).
-  constexpr int PULL_GROUP = 4;
-  int32_t* const d_flip = d_misc + 24;
+  // (16 per group: a settling takes 8-26 passes, so ONE round trip usually decides it; the passes launched after
+  // the settling one find nothing dirty: 16 x 2-3 us against 45 us per extra round trip with groups of four)
+  constexpr int PULL_GROUP = 16;
+  int32_t* const d_flip = d_misc + 32;
+  int32_t* const h_flip = h_flags + 32;
   auto propagate = [&]() -> int {
     for (int it = 0; it < 1000000; it++) {
       BS_HIP(ctx, hipMemsetAsync(d_flip, 0, sizeof(int32_t) * PULL_GROUP, st));
@@ -2424,9 +2447,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         std::swap(dcur, dnext);  // dcur now holds the newly dirtied points (the old dcur was cleared by the pass)
         std::swap(bcur, bnext);
       }
-      BS_HIP(ctx, hipMemcpyAsync(h_flags, d_flip, sizeof(int32_t) * PULL_GROUP, hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipMemcpyAsync(h_flip, d_flip, sizeof(int32_t) * PULL_GROUP, hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
-      if (!h_flags[PULL_GROUP - 1]) {
+      if (!h_flip[PULL_GROUP - 1]) {
         if (getenv("BS_VERIFY")) {
           BS_HIP(ctx, hipMemsetAsync(d_misc + 3, 0, sizeof(int), st));
           verify_fixpoint_kernel<<<nblk(n, 256), 256, 0, st>>>(n, hmask, prio, ps, base, roff, radj, omega, occ, d_misc + 3);
@@ -2508,14 +2531,20 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   }
   int32_t rejects_seen = 0;
   int refused_rounds = 0;
+  int64_t incons[3] = {0, 0, 0};
   int forge_mode = ctx->forge_mode;
   ctx->forge_mode = 0;
   const int lds_pad = getenv("BS_GROW_LDS_PAD") ? atoi(getenv("BS_GROW_LDS_PAD")) : 0;  // experiment: unused dynamic LDS lowers the occupancy
   const bool dbg = getenv("BS_DEBUG") != nullptr;  // (not once per attempt: 158 k of them in a first round)
   const bool do_validate3 = getenv("BS_NO_VALIDATE3") == nullptr;  // developer A/B switch
-  // Step engine: grow_spec2_kernel (hot loop + complete step); BS_GROW_V2=0 selects the first-generation kernel (A/B).
-  const bool grow_v1 = getenv("BS_GROW_V2") != nullptr && atoi(getenv("BS_GROW_V2")) == 0;
-  BS_HIP(ctx, hipMemsetAsync(d_misc + 4, 0, 3 * sizeof(int), st));  // [4] refused planes, [5] forged seed + 1, [6] forged one refused
+  // Step engine.  grow_spec2_kernel (hot loop + complete step) is ~8 % faster per step on a chain of steps served
+  // from L2 / Infinity Cache (facade 1 M: 136.7 vs 147.8 ms of growth kernels) but needs more registers: with k > 16
+  // (255 VGPRs, one wave per SIMD) and in rounds with tens of thousands of attempts, where the throughput of the
+  // many short attempts counts and the long chains wait for HBM anyway (urban 10 M k=32: 128 vs 112 ms, urban 50 M:
+  // 199.5 vs 184.8 ms), the first engine wins.  So: second engine for rounds of few attempts at k <= 16.
+  // BS_GROW_V2=0 / 1 forces one of them (A/B runs, tests).
+  const int grow_force = getenv("BS_GROW_V2") ? atoi(getenv("BS_GROW_V2")) : -1;
+  BS_HIP(ctx, hipMemsetAsync(d_misc + 4, 0, 12 * sizeof(int), st));  // [4] refused planes, [5] forged seed + 1, [6] forged one refused, [12..15] refusals by check
   for (;;) {
     rounds++;
     a.F = F;
@@ -2586,6 +2615,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       // is grown again has the time to finish inside the same launch (urban 10 M: +20 %); in a round of a few
       // chained planes (the facade) the re-growth only repeats work the next round does anyway (-23 %).
       const int rml = (ncand >= retry_big_round && !retry_env) ? 0x7fffffff : retry_max_list;
+      const bool grow_v1 = grow_force >= 0 ? grow_force == 0 : !(KC == 16 && ncand < 4096);
       if (grow_v1) {
         if (KC == 16)
           grow_spec_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
@@ -2647,10 +2677,10 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     PlaneOut* d_outh = d_out;
     if (compact) {
       size_t tb = 0;
-      BS_HIP(ctx, hipcub::DeviceSelect::If(nullptr, tb, d_out, d_outc, d_misc + 12, ncand, KeepForHost(), st));
+      BS_HIP(ctx, hipcub::DeviceSelect::If(nullptr, tb, d_out, d_outc, d_misc + 20, ncand, KeepForHost(), st));
       BS_HIP(ctx, ctx->cub_tmp.reserve(tb));
-      BS_HIP(ctx, hipcub::DeviceSelect::If(ctx->cub_tmp.p, tb, d_out, d_outc, d_misc + 12, ncand, KeepForHost(), st));
-      BS_HIP(ctx, hipMemcpyAsync(h_flags + 14, d_misc + 12, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      BS_HIP(ctx, hipcub::DeviceSelect::If(ctx->cub_tmp.p, tb, d_out, d_outc, d_misc + 20, ncand, KeepForHost(), st));
+      BS_HIP(ctx, hipMemcpyAsync(h_flags + 14, d_misc + 20, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       BS_HIP(ctx, hipStreamSynchronize(st));
       nh = h_flags[14];
       d_outh = d_outc;
@@ -2679,6 +2709,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         return fail(ctx, BS_ERR_INTERNAL, "region grow (speculative): watchdog");
       if (o.status == ST_DONE && (!o.consistent || !o.v3ok))
         first_bad = std::min(first_bad, o.seed);
+      if (o.status == ST_DONE && !o.consistent) {  // which test of validate2 failed (PlaneOut.pad4: 1 seed row, 2 list, 4 log)
+        incons[0] += (o.pad4 & 1) ? 1 : 0;
+        incons[1] += (o.pad4 & 2) ? 1 : 0;
+        incons[2] += (o.pad4 & 4) ? 1 : 0;
+      }
       if (o.w == 0 && o.status == ST_NOMEM)
         nomem_lowest = true;
       if (o.status == ST_NOMEM) {
@@ -2865,7 +2900,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
     BS_HIP(ctx, hipMemcpyAsync(ctx->rg_planes.p, recs.data(), sizeof(PlaneRec) * np, hipMemcpyHostToDevice, st));
   }
   label_kernel<<<nblk(n, 256), 256, 0, st>>>(owner_final, n, d_seeds, np, prio, d_plane_idx);
-  int32_t vstat[3] = {0, 0, 0};
+  int32_t vstat[12] = {0};
   BS_HIP(ctx, hipMemcpyAsync(vstat, d_misc + 4, sizeof vstat, hipMemcpyDeviceToHost, st));
   GrowStats hs;
   hs.n_planes = np;
@@ -2891,6 +2926,13 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   ctx->tm.validation_rejects = vstat[0];
   ctx->tm.forged_seed = vstat[1] - 1;
   ctx->tm.forged_refused = vstat[2];
+  ctx->tm.rej_v1_robbed = vstat[8];
+  ctx->tm.rej_v1_tag = vstat[9];
+  ctx->tm.rej_v1_dup = vstat[10];
+  ctx->tm.rej_v3_state = vstat[11];
+  ctx->tm.incons_seed = incons[0];
+  ctx->tm.incons_list = incons[1];
+  ctx->tm.incons_log = incons[2];
   {
     float ms = 0.f;
     ctx->tm.grow_setup_ms = hipEventElapsedTime(&ms, ctx->ev[8], ctx->ev[9]) == hipSuccess ? (double)ms : 0.0;
@@ -2935,6 +2977,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       BS_HIP(ctx, hipMemcpyAsync(d_cand, hc_sorted.data(), sizeof(unsigned long long) * na, hipMemcpyHostToDevice, st));
     a.F = INF;
     auto grow_n = [&](int off, int cnt, PlaneOut* o) {
+      const bool grow_v1 = grow_force >= 0 ? grow_force == 0 : !(KC == 16 && cnt < 4096);
       if (grow_v1) {
         if (KC == 16)
           grow_spec_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
@@ -2947,22 +2990,52 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
           grow_spec2_kernel<32><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
       }
     };
-    auto compare_n = [&](int cnt) {
+    auto compare_n = [&](int cnt, int32_t* retry) {
       audit_compare_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, prio, d_seeds, ctx->rg_planes.as<PlaneRec>(), np,
-                                               ctx->rg_list.as<int32_t>(), a.th_count, d_misc + 8);
+                                               ctx->rg_list.as<int32_t>(), a.th_count, d_misc + 8, dead, retry);
     };
     for (int off = 0; off < n_committed; off += wave_cap) {
       const int cnt = std::min(n_committed - off, wave_cap);
       BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
       grow_n(off, cnt, d_out);
-      compare_n(cnt);
+      compare_n(cnt, nullptr);
       reset_tags_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, rec, quads, K);
     }
-    for (int i = n_committed; i < na; i++) {  // one at a time, each with the whole pool to itself
-      BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
-      grow_n(i, 1, d_out);
-      compare_n(1);
-      reset_tags_kernel<<<1, VT, 0, st>>>(d_out, 1, pool.base, rec, quads, K);
+    // Attempts the reference rolled back (:203-208): a few hundred points each.  They gave their points free again, so
+    // two of them (or one and a later plane) may want the same point: all of them are replayed CONCURRENTLY, and those
+    // that met another attempt of the batch -- robbed, or one logged "held by an earlier in-flight attempt" -- are
+    // replayed again in the next batch, on clean tags.  The lowest seed of a batch always comes through, so the
+    // batches shrink; in practice one or two suffice (one launch per attempt before: 0.6 s at 50 M, 3 s at 200 M).
+    {
+      std::vector<unsigned long long> pend(hc_sorted.begin() + n_committed, hc_sorted.end()), next;
+      int32_t* d_retry = reinterpret_cast<int32_t*>(dkeys_in);  // (free outside the rounds: wave_cap words)
+      std::vector<int32_t> h_retry;
+      int batches = 0;
+      while (!pend.empty()) {
+        next.clear();
+        for (size_t off = 0; off < pend.size(); off += (size_t)wave_cap) {
+          const int cnt = (int)std::min<size_t>(pend.size() - off, (size_t)wave_cap);
+          BS_HIP(ctx, hipMemcpyAsync(d_cand, pend.data() + off, sizeof(unsigned long long) * cnt, hipMemcpyHostToDevice, st));
+          BS_HIP(ctx, hipMemsetAsync(d_pool_top, 0, sizeof(unsigned long long), st));
+          reset_dead_kernel<<<nblk(cnt, 256), 256, 0, st>>>(d_cand, cnt, dead);
+          grow_n(0, cnt, d_out);
+          compare_n(cnt, d_retry);
+          reset_tags_kernel<<<cnt, VT, 0, st>>>(d_out, cnt, pool.base, rec, quads, K);
+          reset_dead_kernel<<<nblk(cnt, 256), 256, 0, st>>>(d_cand, cnt, dead);
+          h_retry.resize((size_t)cnt);
+          BS_HIP(ctx, hipMemcpyAsync(h_retry.data(), d_retry, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+          BS_HIP(ctx, hipStreamSynchronize(st));
+          for (int i = 0; i < cnt; i++)
+            if (h_retry[i])
+              next.push_back(pend[off + i]);
+        }
+        if (next.size() == pend.size())
+          return fail(ctx, BS_ERR_INTERNAL, "audit: a batch of rolled-back attempts made no progress");
+        pend.swap(next);
+        batches++;
+      }
+      if (dbg)
+        fprintf(stderr, "[bs] audit: %d rolled-back attempts replayed in %d batches\n", na - n_committed, batches);
     }
     BS_HIP(ctx, hipMemcpyAsync(h_flags + 12, d_misc + 8, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     BS_HIP(ctx, hipStreamSynchronize(st));

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
                                                        int32_t* __restrict__ fb_list,
                                                        int32_t* __restrict__ fb_count, uint64_t cert_r2,
                                                        unsigned long long* __restrict__ uncert,
-                                                       int32_t* __restrict__ npos)
+                                                       int32_t* __restrict__ npos, unsigned long long* __restrict__ tie_rows)
 {
   const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
   if (s >= g.n)
@@ -103,6 +103,9 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
   const int32_t loc = g.slocal[s];
   if (loc < q_begin || loc >= q_end)
     return;
+  // runner-up: the smallest key that is NOT in the list (only needed when the list fills every slot, K == KC):
+  // the (K+1)-th neighbour decides whether the list's boundary is an equal-d^2 tie
+  uint64_t runner = ~0ull;
   const int4 P = g.spts[s];
   const int q[3] = {P.x, P.y, P.z};
   const int ci[3] = {(int)((uint32_t)(P.x - g.mn[0]) / (uint32_t)g.cell),
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
                 pay = ph;
               }
             }
+            runner = key < runner ? key : runner;  // key: the candidate itself if it was not admitted, else what it pushed out
             if ((double)d2 < r2)
               moments_add(m, c.x, c.y, c.z);
           }
@@ -212,225 +216,20 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
   }
   if (cert_r2 && (kth_final >> 32) >= cert_r2)
     atomicAdd(uncert, 1ull);
-}
-
-// ---- LDS-staged tile kernel ---------------------------------------------------------
-// One workgroup = 256 consecutive queries of the cell-sorted order (one compact
-// patch of space).  The union of the 27-cell neighbourhoods of the patch is staged
-// ONCE into LDS -- an LDS hash of the needed cells (filled by the first query of
-// every cell), one global table probe per distinct cell, then coalesced copies of
-// the cells' contiguous point runs -- and all 256 queries do rings 0..1 out of LDS.
-// Queries that need ring 2 continue from HBM/L2 inside the same thread; patches
-// whose neighbourhood does not fit the tile fall back to the untiled path.
-// Bit-identical to knn_fast_kernel (same parity tests), but MEASURED SLOWER on
-// MI355X (1 M points k=16: 1.00 vs 0.58 ms; 50 M: 51.7 vs 24.3 ms): the cell-sorted
-// order already makes L1/L2 serve the candidates, while staging costs LDS atomics,
-// three barriers and drops occupancy to 2 waves/SIMD (70 KB LDS per workgroup).
-// Kept as an opt-in (BS_KNN_TILED=1) for data sets where the caches lose.
-constexpr int TILE_PTS = 3072;    // 48 KB of int4
-constexpr int TILE_HASH = 1024;   // distinct cells per patch (open addressing)
-
-struct TileCell {
-  unsigned long long key;  // packed cell coords, ~0 = free slot
-  int32_t off;             // first point in the tile, -1: cell is empty in the cloud
-  int32_t cnt;
-};
-
-template <int KC>
-__device__ __forceinline__ void knn_consider(const int4 c, const int q[3], double r2, uint64_t (&best)[KC], Moments& m)
-{
-  const int ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
-  const uint32_t d2 = (uint32_t)(ex * ex) + (uint32_t)(ey * ey) + (uint32_t)(ez * ez);
-  uint64_t key = ((uint64_t)d2 << 32) | (uint32_t)c.w;
-  if (key < best[KC - 1]) {
+  if (tie_rows) {
+    // tie exposure: an equal-d^2 pair inside the k-list or at its boundary -- the only rows where
+    // the reference's kd-tree traversal order can differ from this build's canonical (d^2, index) order
+    bool tie = false;
+    uint64_t next = runner;  // the (K+1)-th neighbour: slot K of the register list when K < KC
 #pragma unroll
-    for (int j = 0; j < KC; j++) {
-      const bool lt = key < best[j];
-      const uint64_t hi = lt ? best[j] : key;
-      best[j] = lt ? key : best[j];
-      key = hi;
+    for (int j = 0; j + 1 < KC; j++) {
+      tie = tie || (j + 1 < K && (best[j] >> 32) == (best[j + 1] >> 32));
+      next = (j + 1 == K) ? best[j + 1] : next;
     }
+    tie = tie || (next != ~0ull && (next >> 32) == (kth_final >> 32));
+    if (tie)
+      atomicAdd(tie_rows, 1ull);
   }
-  if ((double)d2 < r2)
-    moments_add(m, c.x, c.y, c.z);
-}
-
-template <int KC>
-__global__ __launch_bounds__(256) void knn_tile_kernel(GridDev g, int64_t q_begin, int64_t q_end, int K, int max_nn,
-                                                       double r2, int32_t* __restrict__ neigh,
-                                                       double* __restrict__ normals, int32_t* __restrict__ fb_list,
-                                                       int32_t* __restrict__ fb_count, uint64_t cert_r2,
-                                                       unsigned long long* __restrict__ uncert)
-{
-  __shared__ int4 tile[TILE_PTS];
-  __shared__ TileCell th[TILE_HASH];
-  __shared__ int32_t th_gstart[TILE_HASH];
-  __shared__ unsigned long long skey[256];
-  __shared__ int tile_n, overflow;
-  const int tid = threadIdx.x;
-  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + tid;
-  const bool inb = s < g.n;
-  int4 P = make_int4(0, 0, 0, 0);
-  int32_t loc = -1;
-  if (inb) {
-    P = g.spts[s];
-    loc = g.slocal[s];
-  }
-  const int q[3] = {P.x, P.y, P.z};
-  const int ci[3] = {(int)((uint32_t)(P.x - g.mn[0]) / (uint32_t)g.cell),
-                     (int)((uint32_t)(P.y - g.mn[1]) / (uint32_t)g.cell),
-                     (int)((uint32_t)(P.z - g.mn[2]) / (uint32_t)g.cell)};
-  const bool isq = inb && loc >= q_begin && loc < q_end;
-  for (int i = tid; i < TILE_HASH; i += 256) {
-    th[i].key = ~0ull;
-    th[i].off = -1;
-    th[i].cnt = 0;
-  }
-  if (tid == 0) {
-    tile_n = 0;
-    overflow = 0;
-  }
-  skey[tid] = isq ? pack_cell((uint32_t)ci[0], (uint32_t)ci[1], (uint32_t)ci[2]) : ~0ull;
-  __syncthreads();
-  // 1. the first query of every cell registers the 27 cells it needs
-  if (isq && (tid == 0 || skey[tid - 1] != skey[tid])) {
-    for (int dz = -1; dz <= 1; dz++)
-      for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
-          const int cx = ci[0] + dx, cy = ci[1] + dy, cz = ci[2] + dz;
-          if (cx < 0 || cy < 0 || cz < 0 || cx >= g.dim[0] || cy >= g.dim[1] || cz >= g.dim[2])
-            continue;
-          const unsigned long long k = pack_cell((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);
-          uint32_t h = hash_cell(k) & (TILE_HASH - 1);
-          int probes = 0;
-          for (;;) {
-            const unsigned long long prev = atomicCAS(&th[h].key, ~0ull, k);
-            if (prev == ~0ull || prev == k)
-              break;
-            h = (h + 1) & (TILE_HASH - 1);
-            if (++probes >= TILE_HASH - 1) {
-              overflow = 1;
-              break;
-            }
-          }
-        }
-  }
-  __syncthreads();
-  // 2. one global table probe per distinct cell; reserve its run in the tile
-  for (int i = tid; i < TILE_HASH; i += 256) {
-    const unsigned long long k = th[i].key;
-    if (k == ~0ull)
-      continue;
-    int cs, ce;
-    if (cell_lookup(g, (uint32_t)(k & 0x1FFFFF), (uint32_t)((k >> 21) & 0x1FFFFF), (uint32_t)(k >> 42), cs, ce)) {
-      const int cnt = ce - cs;
-      const int off = atomicAdd(&tile_n, cnt);
-      if (off + cnt > TILE_PTS) {
-        overflow = 1;
-      } else {
-        th[i].off = off;
-        th[i].cnt = cnt;
-        th_gstart[i] = cs;
-      }
-    }
-  }
-  __syncthreads();
-  const bool tiled = overflow == 0;
-  // 3. coalesced copies of the cells' point runs (16 lanes per cell)
-  if (tiled) {
-    const int grp = tid >> 4, gl = tid & 15;
-    for (int i = grp; i < TILE_HASH; i += 16) {
-      const int cnt = th[i].cnt;
-      if (cnt <= 0)
-        continue;
-      const int off = th[i].off, gs = th_gstart[i];
-      for (int j = gl; j < cnt; j += 16)
-        tile[off + j] = g.spts[gs + j];
-    }
-  }
-  __syncthreads();
-  if (!isq)
-    return;
-  uint64_t best[KC];
-#pragma unroll
-  for (int j = 0; j < KC; j++)
-    best[j] = ~0ull;
-  Moments m = {};
-  bool done = false;
-  for (int rho = 0; rho <= BS_FAST_RINGS && !done; rho++) {
-    for (int dz = -rho; dz <= rho; dz++) {
-      const int cz = ci[2] + dz;
-      if (cz < 0 || cz >= g.dim[2])
-        continue;
-      for (int dy = -rho; dy <= rho; dy++) {
-        const int cy = ci[1] + dy;
-        if (cy < 0 || cy >= g.dim[1])
-          continue;
-        const bool face = (dz == -rho || dz == rho || dy == -rho || dy == rho);
-        const int step = face ? 1 : (rho > 0 ? 2 * rho : 1);
-        for (int dx = -rho; dx <= rho; dx += step) {
-          const int cx = ci[0] + dx;
-          if (cx < 0 || cx >= g.dim[0])
-            continue;
-          // one candidate loop for both sources (a second copy of the sorted
-          // insertion network would double the register footprint)
-          int off = 0, cnt = 0;
-          const bool from_lds = tiled && rho <= 1;
-          if (from_lds) {
-            const unsigned long long k = pack_cell((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);
-            uint32_t h = hash_cell(k) & (TILE_HASH - 1);
-            while (th[h].key != k)  // registered in step 1: always found
-              h = (h + 1) & (TILE_HASH - 1);
-            off = th[h].off;
-            cnt = th[h].cnt;
-          } else {
-            int cs, ce;
-            if (cell_lookup(g, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce)) {
-              off = cs;
-              cnt = ce - cs;
-            }
-          }
-          for (int t = 0; t < cnt; t++) {
-            const int4 c = from_lds ? tile[off + t] : g.spts[off + t];
-            knn_consider<KC>(c, q, r2, best, m);
-          }
-        }
-      }
-    }
-    uint64_t R2;
-    const bool bounded = guaranteed_radius(g, q, ci, rho, R2);
-    if (!bounded) {
-      done = true;
-    } else {
-      uint64_t kth = ~0ull;
-#pragma unroll
-      for (int j = 0; j < KC; j++)
-        kth = (j == K - 1) ? best[j] : kth;
-      done = kth != ~0ull && (kth >> 32) < R2 && (double)R2 >= r2;
-    }
-  }
-  uint64_t kth_final = ~0ull;
-#pragma unroll
-  for (int j = 0; j < KC; j++)
-    kth_final = (j == K - 1) ? best[j] : kth_final;
-  if (!done || m.n > max_nn || kth_final == ~0ull) {
-    fb_list[atomicAdd(fb_count, 1)] = (int32_t)s;
-    return;
-  }
-  int32_t* row = neigh + (int64_t)(loc - q_begin) * K;
-#pragma unroll
-  for (int j = 0; j < KC; j++)
-    if (j < K)
-      row[j] = (int32_t)(uint32_t)best[j];
-  if (normals) {
-    const V3 nv = normal_from_moments(m);
-    double* o = normals + 3 * (int64_t)(loc - q_begin);
-    o[0] = nv.x;
-    o[1] = nv.y;
-    o[2] = nv.z;
-  }
-  if (cert_r2 && (kth_final >> 32) >= cert_r2)
-    atomicAdd(uncert, 1ull);
 }
 
 // ---- general exact path: explicit sorted lists in scratch -------------------
@@ -440,13 +239,19 @@ __device__ inline bool cand_less(uint64_t d2a, int32_t ia, uint64_t d2b, int32_t
   return d2a < d2b || (d2a == d2b && ia < ib);
 }
 
+// (*out_d2: the smallest d^2 that did NOT stay in the list so far -- the candidate itself or what it pushed out)
 __device__ inline void list_insert(uint64_t* d2s, int32_t* idxs, int32_t* poss, int& cnt, int cap, uint64_t d2, int32_t idx,
-                                   int32_t pos)
+                                   int32_t pos, uint64_t* out_d2 = nullptr)
 {
   int c = cnt;
   if (c == cap) {
-    if (!cand_less(d2, idx, d2s[cap - 1], idxs[cap - 1]))
+    if (!cand_less(d2, idx, d2s[cap - 1], idxs[cap - 1])) {
+      if (out_d2 && d2 < *out_d2)
+        *out_d2 = d2;
       return;
+    }
+    if (out_d2 && d2s[cap - 1] < *out_d2)
+      *out_d2 = d2s[cap - 1];
     c = cap - 1;
   }
   int j = c;
@@ -492,7 +297,7 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
                                                          const int32_t* __restrict__ fb_count,
                                                          uint64_t cert_r2,
                                                          unsigned long long* __restrict__ uncert,
-                                                         int32_t* __restrict__ npos)
+                                                         int32_t* __restrict__ npos, unsigned long long* __restrict__ tie_rows)
 {
   const int total = *fb_count;
   for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += gridDim.x * blockDim.x) {
@@ -506,6 +311,7 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
     uint64_t kd2[32], md2[64];
     int32_t kidx[32], kpos[32], mgid[64], mpos[64];
     int kc = 0, mc = 0;
+    uint64_t runner = ~0ull;  // d^2 of the (K+1)-th neighbour once the scan is complete
     bool done = false;
     for (int rho = 0; rho <= BS_GENERAL_RINGS && !done; rho++) {
       for (int dz = -rho; dz <= rho; dz++) {
@@ -529,7 +335,7 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
               const int4 c = g.spts[t];
               const int64_t ex = (int64_t)c.x - q[0], ey = (int64_t)c.y - q[1], ez = (int64_t)c.z - q[2];
               const uint64_t d2 = (uint64_t)(ex * ex) + (uint64_t)(ey * ey) + (uint64_t)(ez * ez);
-              list_insert(kd2, kidx, kpos, kc, K, d2, c.w, t);
+              list_insert(kd2, kidx, kpos, kc, K, d2, c.w, t, &runner);
               if ((double)d2 < r2)
                 hybrid_insert(md2, mgid, mpos, mc, max_nn, d2, c.w, t);
             }
@@ -547,11 +353,12 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
       // full scan of the cloud: always exact
       kc = 0;
       mc = 0;
+      runner = ~0ull;
       for (int64_t t = 0; t < g.n; t++) {
         const int4 c = g.spts[t];
         const int64_t ex = (int64_t)c.x - q[0], ey = (int64_t)c.y - q[1], ez = (int64_t)c.z - q[2];
         const uint64_t d2 = (uint64_t)(ex * ex) + (uint64_t)(ey * ey) + (uint64_t)(ez * ez);
-        list_insert(kd2, kidx, kpos, kc, K, d2, c.w, (int32_t)t);
+        list_insert(kd2, kidx, kpos, kc, K, d2, c.w, (int32_t)t, &runner);
         if ((double)d2 < r2)
           hybrid_insert(md2, mgid, mpos, mc, max_nn, d2, c.w, (int32_t)t);
       }
@@ -582,6 +389,13 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
     }
     if (cert_r2 && kd2[K - 1] >= cert_r2)
       atomicAdd(uncert, 1ull);
+    if (tie_rows) {
+      bool tie = runner == kd2[K - 1];
+      for (int j = 0; j + 1 < K; j++)
+        tie = tie || kd2[j] == kd2[j + 1];
+      if (tie)
+        atomicAdd(tie_rows, 1ull);
+    }
   }
 }
 
@@ -608,6 +422,7 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
   int32_t* fb_list = ctx->fb_list.as<int32_t>() + 16;
   int32_t* fb_count = ctx->fb_list.as<int32_t>();
   unsigned long long* uncert = (unsigned long long*)(ctx->fb_list.as<int32_t>() + 4);
+  unsigned long long* tie_rows = (unsigned long long*)(ctx->fb_list.as<int32_t>() + 8);
   BS_HIP(ctx, hipMemsetAsync(ctx->fb_list.p, 0, 64, st));
   const double r2 = p.radius * p.radius;
   uint64_t cert_r2 = 0;
@@ -622,37 +437,30 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
   // fast kernel needs every candidate d^2 < 2^32
   const bool fast_ok = (int64_t)g.cell * (2 * BS_FAST_RINGS + 1) <= 37500;
   if (fast_ok) {
-    // measured on MI355X: the LDS-staged variant is slower than the cache-served one
-    // (1 M: 1.00 vs 0.58 ms, 50 M: 51.7 vs 24.3 ms) -- opt-in only
-    const bool untiled = getenv("BS_KNN_TILED") == nullptr || d_npos != nullptr;  // (the tiled variant emits no positions)
-    if (p.k <= 16) {
-      if (untiled)
-        knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                    fb_list, fb_count, cert_r2, uncert, d_npos);
-      else
-        knn_tile_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                    fb_list, fb_count, cert_r2, uncert);
-    } else {
-      if (untiled)
-        knn_fast_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                    fb_list, fb_count, cert_r2, uncert, d_npos);
-      else
-        knn_tile_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                    fb_list, fb_count, cert_r2, uncert);
-    }
+    // (an LDS-staged tile variant -- the 27-cell neighbourhood of 256 consecutive queries staged once per workgroup --
+    // was measured slower on MI355X, 1 M points: 1.00 vs 0.58 ms, 50 M: 51.7 vs 24.3 ms, and is retired: the cell-sorted
+    // order already makes L1 / L2 serve the candidates, while staging costs LDS atomics, three barriers and occupancy)
+    if (p.k <= 16)
+      knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                  fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
+    else
+      knn_fast_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                  fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
   } else {
     mark_all_kernel<<<blocks, 256, 0, st>>>(g, q_begin, q_end, fb_list, fb_count);
   }
   knn_general_kernel<<<1024, 64, 0, st>>>(g, q_begin, p.k, p.max_nn, r2, d_neigh, d_normals, fb_list,
-                                          fb_count, cert_r2, uncert, d_npos);
+                                          fb_count, cert_r2, uncert, d_npos, tie_rows);
   BS_HIP(ctx, hipGetLastError());
   // bookkeeping read-back (also the point where kernel faults surface)
   int32_t hb[4];
   BS_HIP(ctx, hipMemcpyAsync(hb, ctx->fb_list.p, sizeof hb, hipMemcpyDeviceToHost, st));
-  unsigned long long hu = 0;
+  unsigned long long hu = 0, ht = 0;
   BS_HIP(ctx, hipMemcpyAsync(&hu, uncert, sizeof hu, hipMemcpyDeviceToHost, st));
+  BS_HIP(ctx, hipMemcpyAsync(&ht, tie_rows, sizeof ht, hipMemcpyDeviceToHost, st));
   BS_HIP(ctx, hipStreamSynchronize(st));
   ctx->tm.n_fallback_queries = hb[0];
+  ctx->tm.tie_rows = (int64_t)ht;
   if (n_uncertified)
     *n_uncertified = (int64_t)hu;
   return BS_OK;

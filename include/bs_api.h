@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BS_API_VERSION 4
+#define BS_API_VERSION 5
 
 typedef enum bs_status {
   BS_OK = 0,
@@ -97,7 +97,22 @@ typedef struct bs_timings {
   int64_t audit_attempts;     /* bs_set_audit: plane attempts replayed against the final owners (-1: audit off) */
   int64_t audit_mismatches;   /* ... of which differ from what was committed (must be 0) */
   double audit_ms;            /* time of the replay + comparison (not part of grow_ms / total_ms) */
+  /* -- API version 5 -- */
+  int64_t tie_rows;           /* queries of the last kNN call whose k-list has an equal-d^2 pair inside it or at its
+                                 boundary (k-th vs (k+1)-th neighbour): the only rows where the reference's kd-tree
+                                 traversal order may differ from this library's canonical (d^2, index) order */
+  /* why the post-round validation refused finished planes (every refused plane is grown again; the result stays
+   * exact).  validate1: the plane was robbed after it finished / a list entry no longer carries its claim / a point
+   * is listed twice; validate3: normal or centre not reproducible from the list. */
+  int64_t rej_v1_robbed, rej_v1_tag, rej_v1_dup, rej_v3_state;
+  /* finished planes that were merely INCONSISTENT with the settled owners (normal outcome of the speculation, not
+   * a refusal): seed row no longer free / an accepted point was taken earlier / a logged assumption failed */
+  int64_t incons_seed, incons_list, incons_log;
 } bs_timings;
+
+/* sizeof(bs_timings) of the library build: a host compiled against another header version must not call
+ * bs_get_timings (the struct is written whole).  host/bs_legacy.hpp and the Python loader check it. */
+int64_t bs_sizeof_timings(void);
 
 typedef struct bs_ctx bs_ctx;
 

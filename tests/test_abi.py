@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     for name in _declared():
         assert hasattr(L, name), name
-    assert L.bs_api_version() == 4
+    assert L.bs_api_version() == 5 == _lib.API_VERSION
+    assert L.bs_sizeof_timings() == C.sizeof(_lib.Timings)
     assert L.bs_strerror(0) == b"ok" and b"2^23" in L.bs_strerror(-2)
 
 

@@ -71,14 +71,17 @@ def check_properties(xyz, k, neigh, normals, plane_idx, planes, th_count=400):
         assert np.array_equal(S / nrm, pl.normal), (t, S / nrm, pl.normal)
 
 
-@pytest.mark.parametrize("workload", ["facade_1m", "urban_10m", "urban_50m"])
-def test_fullsize_digests_and_properties(gpu_ctx, workload):
+# (NAME_k15: the same cloud with the reference's own literals K = 15, r = 100, max_nn = 50 -- TMC3.cpp:215-216)
+@pytest.mark.parametrize("key", ["facade_1m", "urban_10m", "urban_50m", "facade_1m_k15", "urban_10m_k15"])
+def test_fullsize_digests_and_properties(gpu_ctx, key):
     import bench
     from buildingsegment_amd import api
-    gold = json.load(open(GOLD))[workload]
+    gold = json.load(open(GOLD))[key]
+    workload = gold["workload"]
     t0 = time.time()
     xyz, k = bench.make_cloud(workload)
-    assert len(xyz) == gold["n"] and k == gold["k"]
+    k = gold["k"]
+    assert len(xyz) == gold["n"]
     assert sha(xyz) == gold["xyz"], "synthetic generator drifted: regenerate tests/golden/digests.json"
     print(f"\n[{workload}] cloud {time.time() - t0:.1f}s", flush=True)
     t0 = time.time()
@@ -109,6 +112,9 @@ def test_fullsize_digests_and_properties(gpu_ctx, workload):
     assert sha(np.stack([p.normal for p in planes])) == gold["plane_normal_bits"]
     assert sha(np.stack([p.center for p in planes]).astype(np.int32)) == gold["plane_center"]
     assert tm["n_seed_attempts"] >= len(planes)
+    if "tie_rows" in gold:  # exposure to the reference's kd-tree tie order: the same count as the CPU oracle's
+        assert tm["tie_rows"] == gold["tie_rows"], (tm["tie_rows"], gold["tie_rows"])
+        print(f"[{workload}] tie rows: {tm['tie_rows']} of {len(xyz)} ({100.0 * tm['tie_rows'] / len(xyz):.3f} %)", flush=True)
     t0 = time.time()
     check_properties(xyz, k, neigh, normals, plane_idx, planes)
     print(f"[{workload}] properties {time.time() - t0:.1f}s", flush=True)

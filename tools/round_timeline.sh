@@ -2,11 +2,11 @@
 # tools/round_timeline.sh <workload>: per-round wall-clock anatomy of stage 3 from a rocprofv3 kernel trace of ONE pass:
 # growth kernel ms, the gap until the next growth launch (validation, owner passes, host round trips), owner passes in it
 export TMPDIR=/tmp BS_CLOUD_CACHE=/tmp
-mkdir -p gpurun_out/r02; rm -rf gpurun_out/r02/kt
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r02/kt -- python3 bench.py --workload $1 --steps 1 --warmup 1 --secondary= --no-cpu-baseline --no-audit --concurrent 0 > /dev/null 2>&1 || exit 1
+mkdir -p gpurun_out/r03; rm -rf gpurun_out/r03/kt
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r03/kt -- python3 bench.py --workload $1 --steps 1 --warmup 1 --secondary= --no-cpu-baseline --no-audit --concurrent 0 > /dev/null 2>&1 || exit 1
 python3 - <<PY
 import csv, glob
-f = glob.glob('gpurun_out/r02/kt/*/*kernel_trace.csv')[0]
+f = glob.glob('gpurun_out/r03/kt/*/*kernel_trace.csv')[0]
 rows = sorted(({'n': r['Kernel_Name'], 's': int(r['Start_Timestamp']), 'e': int(r['End_Timestamp'])} for r in csv.DictReader(open(f))), key=lambda r: r['s'])
 # keep the LAST pass: starts at the last cellkey/grid kernel burst before the last build_records
 br = [i for i, r in enumerate(rows) if 'build_records' in r['n']]
@@ -29,4 +29,4 @@ for k, i in enumerate(gs):
         k + 1, g, gap, busy, npull, pull, max([0] + [(r['e'] - r['s']) // 1000 for r in seg if 'pull_pass' in r['n']]), len(seg) - npull))
 print('sum grow %.1f ms, sum gaps %.1f ms (kernel-busy %.1f ms)' % (tot_g, tot_gap, tot_busy))
 PY
-rm -rf gpurun_out/r02/kt
+rm -rf gpurun_out/r03/kt
