@@ -1188,7 +1188,15 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
 //  * the candidates' neighbour rows fetched cooperatively (four lanes per row, 16 cache lines per instruction
 //    instead of 60, rows kept in that layout until the LDS push): 150-159 ms -- the four extra LIFO reads for the
 //    row duty and the issue of the re-addressed loads cost more than the saved line look-ups;
-//  * a single-exit loop (decide `commit` first, apply under one branch): 146.9 ms.
+//  * a single-exit loop (decide `commit` first, apply under one branch): 146.9 ms;
+//  * an LDS bitmap of the points this plane already holds (no record fetched for them: their lanes share one cache
+//    line; a step that only sees own points needs no memory access): 145.6 ms -- the time from the issue of the gather
+//    to its data (~1 150 cycles together with the plane-state arithmetic under it) does not depend on how many lanes
+//    fetch distinct lines;
+//  * the claim tags in an array of their own instead of inside the 128-byte records (so that the claims' memory-side
+//    atomics would not throw the records' lines out of L2): first engine 149.3 vs 147.8 ms -- neutral.
+// What bounds a step is the length of the wave's dependent instruction chain (pop -> addresses -> gather -> f64 test
+// -> votes -> claims -> push, ~330 instructions at ~9 cycles each for a wave alone on its SIMD), not the memory level.
 constexpr int LBUF = 256;  // LDS ring of pointIdx entries (flushed in bursts of 64)
 #ifdef BS_PROBE
 // cycle stamps between the phases of a step (developer build: tools/probe_grow2.sh); planes with > 20 000 entries
