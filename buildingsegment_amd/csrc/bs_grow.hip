@@ -127,7 +127,21 @@ __global__ __launch_bounds__(64) void grow_seq_kernel(GrowArgs a)
         const double dt = cnx * mx + cny * my + cnz * mz;
         ok = dist <= a.th && dt >= a.cos_th;  // :230
       }
-      const unsigned long long am = __ballot(ok);
+      unsigned long long am = __ballot(ok);
+      {
+        // a caller-supplied row may repeat an index: the reference labels the point on first sight and finds it labelled
+        // on the second (:226-233), so only the LOWEST accepting lane of an index keeps it
+        bool dup = false;
+        unsigned long long mm = am;
+        while (mm) {
+          const int l = __ffsll(mm) - 1;
+          mm &= mm - 1;
+          const int cl = readlane_i32(cand, l);
+          dup = dup || (l < lane && cl == cand);
+        }
+        ok = ok && !dup;
+        am = __ballot(ok);
+      }
       const int cnt = __popcll(am);
       if (ok)
         a.plane_idx[cand] = cur_id;  // :233

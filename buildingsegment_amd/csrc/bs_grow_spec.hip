@@ -228,6 +228,8 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
     uint32_t m = 0, lm = 0;  // lm: bit t-1 set when this point precedes neighbour t in the original order
     for (int t = 1; t < a.K; t++) {
       const int32_t c = row[t];
+      if (c < 0)
+        continue;  // a repeated index of a caller-supplied row (see build_records_kernel): no neighbour
       const int64_t gd = (int64_t)c - g0;
       int4 q0, q1, q2;
       if (gd >= 0 && gd < GW_WIN) {
@@ -699,6 +701,21 @@ __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ ord
     }
     row[j] = v;
   }
+  if (!npos) {
+    // Caller-supplied rows may repeat an index in slots 1..K-1.  The reference labels a point on first sight and finds
+    // it labelled on the second (my_function.cpp:226-233): the repeat is a no-op, and a seed with a repeat can never
+    // collect K-1 accepted neighbours (:238).  The repeat becomes -1 = "no neighbour": the lane is idle in every Broad()
+    // call, the static mask of the point is incomplete (never a plane seed), the first occurrence carries the rest.
+    // (Our own k-lists hold distinct indices: the fused pipeline skips this.)
+#pragma unroll
+    for (int j = 2; j < KC; j++) {
+      bool rep = false;
+#pragma unroll
+      for (int t = 1; t < j; t++)
+        rep = rep || (j < a.K && row[t] == row[j]);
+      row[j] = rep ? -1 : row[j];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < KC; j += 4)
     r[4 + j / 4] = make_int4(row[j], row[j + 1], row[j + 2], row[j + 3]);
@@ -882,6 +899,8 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
       int cand_id = 0;
       if (valid && act)
         cand_id = lds_stack[(e & (LDS_STACK - 1)) * KC + j + 1];
+      const bool live = cand_id >= 0;  // (-1: repeated index of a caller-supplied row, no neighbour)
+      cand_id = live ? cand_id : 0;
       const int killed = ld_i32(dead + seed);  // an earlier plane took one of my points: I am invalid
       const int vt = ld_i32(pendv ? vptr : dead + seed);  // read-back of the previous call's claim
       int own = 0, tg = INF, px = 0, py = 0, pz = 0;
@@ -918,7 +937,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
           update_state();
       }
       bool geo = false;
-      if (valid && act && tg != seed) {  // tg == seed: already labelled by this plane
+      if (valid && act && live && tg != seed) {  // tg == seed: already labelled by this plane
         const int dx = (int)((uint32_t)px - (uint32_t)ccx);
         const int dy = (int)((uint32_t)py - (uint32_t)ccy);
         const int dz = (int)((uint32_t)pz - (uint32_t)ccz);
@@ -1324,6 +1343,7 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         // a read under `if` costs an exec-mask branch each, five of them in a row at the head of every step
         {
           const int v = lds_stack[(e & (LDS_STACK - 1)) * KC + ((j + 1) & (KC - 1))];
+          E.valid = E.valid && v >= 0;  // (-1: repeated index of a caller-supplied row, no neighbour)
           E.cand_id = (E.valid && act) ? v : 0;
         }
         // EVERY vector-memory instruction of the hot loop is issued from inline assembly and waited for by the ONE
@@ -2531,6 +2551,17 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   bool cand_listed = false;
   int32_t ncand_all = 0;
   bool v3_pending = false;
+  // validate3 runs on the side stream beside the owner passes: whatever way this function is left (a failed HIP call,
+  // the watchdog, a refused plane), nothing of it may still be in flight on the buffers the next call reuses
+  struct SideGuard {
+    bs_ctx* c;
+    bool* pending;
+    ~SideGuard()
+    {
+      if (*pending && c->side)
+        (void)hipStreamSynchronize(c->side);
+    }
+  } side_guard{ctx, &v3_pending};
   bool dead_dirty = false;
   if (!ctx->side) {
     BS_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));

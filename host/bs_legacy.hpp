@@ -38,6 +38,11 @@ inline bs_ctx* legacy_ctx()
 {
   static bs_ctx* ctx = nullptr;
   if (!ctx) {
+    // the library writes bs_timings whole into caller memory: a host compiled against another header version must
+    // not get that far
+    if (bs_api_version() != BS_API_VERSION || bs_sizeof_timings() != (int64_t)sizeof(bs_timings))
+      throw std::runtime_error("libbuildingsegment_hip.so is API version " + std::to_string(bs_api_version()) +
+                               ", this host was compiled against version " + std::to_string(BS_API_VERSION));
     int rc = bs_create(0, &ctx);
     if (rc != BS_OK)
       throw std::runtime_error(std::string("bs_create: ") + bs_strerror(rc));

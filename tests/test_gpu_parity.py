@@ -484,3 +484,30 @@ def test_region_grow_after_segment_does_not_reuse_the_fused_scratch(gpu_ctx, ora
     assert np.array_equal(pi, opi) and len(planes) == len(opl["id"])
     if planes:
         assert np.array_equal(np.concatenate([q.pointIdx for q in planes]), opl["point_idx"])
+
+
+@pytest.mark.parametrize("rg_mode", [0, 1])
+def test_rows_with_repeated_indices_match_the_reference_semantics(gpu_ctx, oracle, rg_mode):
+    """Caller-supplied k-lists may repeat an index in slots 1..K-1 (bs_region_grow takes any rows).  The reference
+    labels a point on first sight and skips it on the second (my_function.cpp:226-233); a seed with a repeat never
+    reaches K-1 accepted neighbours (:238).  The HIP path must do the same (the fast claim path let both
+    lanes push)."""
+    from buildingsegment_amd import api, synth
+    xyz = synth.boxes(n_boxes=2, seed=33)
+    ng, nr = oracle.knn_normals(xyz, k=15)
+    rng = np.random.default_rng(9)
+    ng = ng.copy()
+    rows = rng.choice(len(xyz), size=len(xyz) // 12, replace=False)
+    dst = rng.integers(2, 15, size=len(rows))
+    src = np.array([rng.integers(1, d) for d in dst])
+    ng[rows, dst] = ng[rows, src]  # slot dst repeats slot src (1 <= src < dst)
+    opi, opl = oracle.region_grow(xyz, nr, ng)
+    pi, planes = gpu_ctx.region_grow(xyz, nr, ng, api.default_params(k=15, rg_mode=rg_mode))
+    assert np.array_equal(pi, opi)
+    assert len(planes) == len(opl["id"])
+    off = opl["offset"]
+    for i, pl in enumerate(planes):
+        assert np.array_equal(pl.pointIdx, opl["point_idx"][off[i]:off[i + 1]])
+        assert np.array_equal(pl.center, opl["center"][i])
+        assert np.array_equal(pl.normal.view(np.int64), opl["normal"][i].view(np.int64))
+    assert (pi > 0).sum() > 1000 and len(planes) >= 1  # the planes still grow around the crippled seeds
