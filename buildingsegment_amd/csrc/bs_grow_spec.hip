@@ -736,6 +736,28 @@ __global__ void refresh_records_kernel(const int32_t* __restrict__ omega, int4* 
   *rec_tag(rec, quads, i) = INF;
 }
 
+// Plane state from the running sums (:249-250): normal = S / |S|, centre = (int32)((uint64)(int64)(int32)C / n).
+// The three components sit in lanes 0..2, so ONE f64 division and ONE size_t division serve all of them (the same
+// IEEE / integer operations on the same operands as three separate ones: same bits).  A free function on values, not
+// part of the step's closure: written inside the lambda the closure fell out of registers (520 B of scratch per lane,
+// every phase of the step 3x slower).
+__device__ __forceinline__ void plane_state_lanes(int lane, double Sx, double Sy, double Sz, uint32_t Cx, uint32_t Cy, uint32_t Cz,
+                                                  uint32_t n, double& cnx, double& cny, double& cnz, int& ccx, int& ccy, int& ccz)
+{
+  const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
+  const double Sv = lane == 0 ? Sx : (lane == 1 ? Sy : Sz);
+  const double qn = Sv / nrm;
+  const CenterDiv cd = center_div_prepare(n);
+  const int32_t Cv = lane == 0 ? (int32_t)Cx : (lane == 1 ? (int32_t)Cy : (int32_t)Cz);
+  const int32_t qc = center_div(Cv, cd);
+  cnx = readlane_f64(qn, 0);
+  cny = readlane_f64(qn, 1);
+  cnz = readlane_f64(qn, 2);
+  ccx = readlane_i32(qc, 0);
+  ccy = readlane_i32(qc, 1);
+  ccz = readlane_i32(qc, 2);
+}
+
 constexpr int LDS_STACK = 256;  // LIFO entries (with rows) kept in LDS
 constexpr int LDS_REFILL = 128;  // entries brought back from HBM when the pops reach below the window
 constexpr int MAX_RETRY_LONG = 3; // ... of which at most this many after a long list was thrown away
@@ -826,14 +848,7 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
       Cy += (uint32_t)readlane_i32(d_py, l);
       Cz += (uint32_t)readlane_i32(d_pz, l);
     }
-    const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
-    cnx = Sx / nrm;
-    cny = Sy / nrm;
-    cnz = Sz / nrm;
-    const CenterDiv cd = center_div_prepare((uint32_t)ln);  // int /= size_t (quirk Q3), see bs_centerdiv.h
-    ccx = center_div((int32_t)Cx, cd);
-    ccy = center_div((int32_t)Cy, cd);
-    ccz = center_div((int32_t)Cz, cd);
+    plane_state_lanes(lane, Sx, Sy, Sz, Cx, Cy, Cz, (uint32_t)ln, cnx, cny, cnz, ccx, ccy, ccz);  // int /= size_t: quirk Q3, bs_centerdiv.h
     need_state = false;
   };
   // first slabs are small: nine attempts in ten fail at depth 0 and never need more
@@ -1390,14 +1405,7 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
             Cy += (uint32_t)readlane_i32(d_py, l);
             Cz += (uint32_t)readlane_i32(d_pz, l);
           }
-          const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
-          cnx = Sx / nrm;
-          cny = Sy / nrm;
-          cnz = Sz / nrm;
-          const CenterDiv cd = center_div_prepare((uint32_t)ln);
-          ccx = center_div((int32_t)Cx, cd);
-          ccy = center_div((int32_t)Cy, cd);
-          ccz = center_div((int32_t)Cz, cd);
+          plane_state_lanes(lane, Sx, Sy, Sz, Cx, Cy, Cz, (uint32_t)ln, cnx, cny, cnz, ccx, ccy, ccz);
           need_state = false;
         }
         PROBE(1);
@@ -1715,14 +1723,7 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         Cy += (uint32_t)readlane_i32(d_py, l);
         Cz += (uint32_t)readlane_i32(d_pz, l);
       }
-      const double nrm = __builtin_sqrt((Sx * Sx) + (Sy * Sy) + (Sz * Sz));
-      cnx = Sx / nrm;
-      cny = Sy / nrm;
-      cnz = Sz / nrm;
-      const CenterDiv cd = center_div_prepare((uint32_t)ln);
-      ccx = center_div((int32_t)Cx, cd);
-      ccy = center_div((int32_t)Cy, cd);
-      ccz = center_div((int32_t)Cz, cd);
+      plane_state_lanes(lane, Sx, Sy, Sz, Cx, Cy, Cz, (uint32_t)ln, cnx, cny, cnz, ccx, ccy, ccz);
       need_state = false;
     }
     if (have_mem && status != ST_NOMEM && !flush_list(ln))  // the whole list is in the HBM slab from here on
