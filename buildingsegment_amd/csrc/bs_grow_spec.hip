@@ -1234,6 +1234,11 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
 //    fetch distinct lines;
 //  * the claim tags in an array of their own instead of inside the 128-byte records (so that the claims' memory-side
 //    atomics would not throw the records' lines out of L2): first engine 149.3 vs 147.8 ms -- neutral.
+//  * the flag / read-back / record loads under exec masks (lane 0 alone reads the killed flag, only claimers read
+//    back, only testing lanes fetch records: ~110 instead of ~550 lane requests per step): the gather came back ~90
+//    cycles earlier, but the three masked regions and the defined-before-asm registers cost 440 cycles at the issue:
+//    146.9 ms;
+//  * one combined test per kind of loop exit instead of separate breaks: 145.0 ms (the back edge grew to 570 cycles).
 // What bounds a step is the length of the wave's dependent instruction chain (pop -> addresses -> gather -> f64 test
 // -> votes -> claims -> push, ~330 instructions at ~9 cycles each for a wave alone on its SIMD), not the memory level.
 constexpr int LBUF = 256;  // LDS ring of pointIdx entries (flushed in bursts of 64)
