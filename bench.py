@@ -161,7 +161,9 @@ def roofline_block(n, k, stage, launches_per_step, rg_mode, workload):
     knn_bytes = n * (4 * k + 36 + 12)
     grow_avg = stage["grow_kernel_ms"] / lps
     if stage["grow_kernel_ms"] >= stage["knn_ms"]:
-        dom = "grow_spec_kernel" if rg_mode != 1 else "grow_seq_kernel"
+        # (the plane-growth launch has two step engines, picked per round: rocprof lists them as two kernels whose
+        # launches together are the `launches_per_step` of this block)
+        dom = "grow_spec_kernel + grow_spec2_kernel" if rg_mode != 1 else "grow_seq_kernel"
         dbytes, dms = grow_bytes, grow_avg
     else:
         dom, dbytes, dms = "knn_fast_kernel", knn_bytes, stage["knn_ms"]
@@ -173,7 +175,7 @@ def roofline_block(n, k, stage, launches_per_step, rg_mode, workload):
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         ent = pt.get(workload) if isinstance(pt.get(workload), dict) else (pt if pt.get("workload") == workload else None)
         if ent and rg_mode != 1:
-            if dom == "grow_spec_kernel":
+            if dom.startswith("grow_spec"):
                 traffic = ent["grow_spec_kernel_bytes_per_call"] / lps
             else:
                 traffic = ent["knn_fast_kernel_bytes_per_call"]

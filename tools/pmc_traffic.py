@@ -37,7 +37,7 @@ def main():
     calls = int(sys.argv[3])
     workload = sys.argv[4]
     merge_into = sys.argv[5] if len(sys.argv) > 5 else None  # existing per-workload JSON to update
-    stage3 = ["grow_spec_kernel", "pull_pass_kernel", "static_mask_kernel", "rev_fill_kernel",
+    stage3 = ["grow_spec_kernel", "grow_spec2_kernel", "pull_pass_kernel", "decide_pass_kernel", "decide_finish_kernel", "static_mask_kernel", "rev_fill_kernel",
               "refresh_records_kernel", "build_records_kernel", "validate1_kernel", "validate2_kernel", "validate3_kernel",
               "plane_apply_kernel", "cand_flag_kernel", "copy_lists_kernel", "label_kernel", "fill_i32_kernel",
               "reset_tags_kernel"]
@@ -51,7 +51,9 @@ def main():
         if k in stage3:
             tot += b
     out["region_grow_stage_bytes_per_call"] = tot
-    out["grow_spec_kernel_bytes_per_call"] = out["kernels"].get("grow_spec_kernel", {}).get("hbm_bytes")
+    # both step engines (grow_spec_kernel, grow_spec2_kernel) are "the growth kernel" of bench.py's roofline block
+    out["grow_spec_kernel_bytes_per_call"] = sum(out["kernels"].get(kn, {}).get("hbm_bytes", 0.0)
+                                                 for kn in ("grow_spec_kernel", "grow_spec2_kernel"))
     out["knn_fast_kernel_bytes_per_call"] = out["kernels"].get("knn_fast_kernel", {}).get("hbm_bytes")
     db = {}
     if merge_into:
