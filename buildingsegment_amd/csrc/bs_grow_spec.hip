@@ -1415,10 +1415,12 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         }
         PROBE(1);
         // ---- the ONE wait of the gather (the operands tie every later use of the data behind it) ----
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(killed_v), "+v"(vt)::"memory");
-#pragma unroll
-        for (int t = 0; t < CH; t++)
-          asm volatile("" : "+v"(E.rows[t]));
+        // (loads return in issue order: with CH still outstanding the five above have landed; the candidates' own rows
+        // are only needed by the push and keep streaming in under the test: rows_wait() below)
+        if (CH == 4)
+          asm volatile("s_waitcnt vmcnt(4)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(killed_v), "+v"(vt)::"memory");
+        else
+          asm volatile("s_waitcnt vmcnt(8)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(killed_v), "+v"(vt)::"memory");
         PROBE(2);
         E.px = q0.x;
         E.py = q0.y;
@@ -1439,6 +1441,18 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         }
         const bool lost = pendv && vt != seed;  // an earlier plane got there first
         E.lost_any = __builtin_amdgcn_readfirstlane(killed_v) != 0 || ballot64(lost) != 0;
+      };
+      // The rows of the candidates are still in flight after eval(): EVERY path from eval() on passes through this wait
+      // before it reads them, issues another vector-memory instruction, or leaves the step (their destination registers
+      // must stay allocated until the loads have landed).
+      auto rows_wait = [&](Ev& E) {
+        static_assert(CH == 4 || CH == 8, "row chunks");
+        if constexpr (CH == 4)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(E.rows[0]), "+v"(E.rows[1]), "+v"(E.rows[2]), "+v"(E.rows[3])::"memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(E.rows[0]), "+v"(E.rows[1]), "+v"(E.rows[2]), "+v"(E.rows[3]), "+v"(E.rows[4]), "+v"(E.rows[5]),
+                         "+v"(E.rows[6]), "+v"(E.rows[7])::"memory");
       };
       // ---- expansion of call gstar (:231-255): list ring, deferred state, children onto the LIFO ----
       auto expand = [&](const Ev& E, bool ok, unsigned long long am, int gstar, int cnt) {
@@ -1494,6 +1508,7 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         }
         Ev E;
         eval(E);
+        rows_wait(E);
         pendv = false;
         if (__builtin_expect(E.lost_any, 0)) {
           status = ST_STOLEN;
@@ -1651,31 +1666,35 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
             break;  // refill
           Ev E;
           eval(E);
-          if (__builtin_expect(E.lost_any, 0)) {
-            pendv = false;
-            status = ST_STOLEN;
-            leave = true;
-            break;
-          }
+          // Classification first, ONE rows_wait() for every way on (a wait per exit made the compiler copy the row
+          // registers -- still being written by the loads -- where the paths meet), then the exits.
           const bool assume = E.geo && E.own < seed && !(E.own < a.F);
           const bool contender = E.geo && !(E.own < seed);
           const unsigned long long cm = ballot64(contender);
           PROBE(3);
           int gstar = -1, cnt = 0;
           unsigned long long am = 0;
+          bool slow = false;
           if (__builtin_expect(cm != 0, 1)) {
             gstar = (__ffsll(cm) - 1) / KC;
             const unsigned long long gm1 = gmask0 << (gstar * KC);
             am = cm & gm1;
             cnt = __popcll(am);
             // everything this loop cannot do is known here, before the first claim is issued
-            const bool slow = (ballot64(contender && E.tg < seed) & gm1) != 0 || ballot64(assume && g <= gstar) != 0 ||
-                              ln + cnt - lflushed > LBUF || sp - (gstar + 1) + cnt - lds_lo > LDS_STACK;
-            if (__builtin_expect(slow, 0))
-              break;
-          } else if (__builtin_expect(ballot64(assume) != 0, 0)) {
-            break;  // only empty calls, but one of them assumed something: the complete step logs it
+            slow = (ballot64(contender && E.tg < seed) & gm1) != 0 || ballot64(assume && g <= gstar) != 0 ||
+                   ln + cnt - lflushed > LBUF || sp - (gstar + 1) + cnt - lds_lo > LDS_STACK;
+          } else {
+            slow = ballot64(assume) != 0;  // only empty calls, but one of them assumed something: the complete step logs it
           }
+          rows_wait(E);  // (before the claims: a wait behind them would put the atomics' round trip on the chain)
+          if (__builtin_expect(E.lost_any, 0)) {
+            pendv = false;
+            status = ST_STOLEN;
+            leave = true;
+            break;
+          }
+          if (__builtin_expect(slow, 0))
+            break;
           // ---- committed: from here on the step has side effects ----
           iters++;
           pendv = false;
