@@ -1222,8 +1222,15 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
 //    256-entry window is full and come back the same way -- no write-through per push;
 //  * pointIdx entries are collected in an LDS ring and leave in coalesced bursts: no store, no address arithmetic
 //    and no slab-capacity check in the step;
-//  * distance and normal test are evaluated side by side (no short circuit).
-// Tried and measured slower (facade 1 M, growth kernels: this engine 136.6 ms, first engine 147.5 ms):
+//  * distance and normal test are evaluated side by side (no short circuit);
+//  * the gather is waited for in two parts: the five loads the test needs (flags, position, normal, tag) first, the
+//    candidates' own rows -- issued last, needed by the push only -- after the classification.  Every scattered
+//    64-lane load costs ~70 cycles of the CU's address unit whatever it hits (tools/probe/gather_probe.hip: 369 cycles
+//    for one, 805 for seven), so the four row loads used to hold the test back by ~280 cycles (facade 131 -> 121 ms).
+//    The rows' registers are written by the hardware after the asm statement that names them: there is ONE wait for
+//    them on every path, and tests/test_isa_rows_wait.py checks in the generated ISA that nothing touches them before.
+// Tried and measured slower (facade 1 M, growth kernels; at the time this engine took 136.6 ms, later 131.2 ms, the
+// first engine 147.5 ms):
 //  * the candidates' neighbour rows fetched cooperatively (four lanes per row, 16 cache lines per instruction
 //    instead of 60, rows kept in that layout until the LDS push): 150-159 ms -- the four extra LIFO reads for the
 //    row duty and the issue of the re-addressed loads cost more than the saved line look-ups;
@@ -1239,6 +1246,14 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
 //    cycles earlier, but the three masked regions and the defined-before-asm registers cost 440 cycles at the issue:
 //    146.9 ms;
 //  * one combined test per kind of loop exit instead of separate breaks: 145.0 ms (the back edge grew to 570 cycles).
+//  * the plane state on a second wave of the workgroup (128 threads: wave 1 keeps the running sums and publishes
+//    normal and centre through LDS, wave 0 traverses): 143.4 vs 131.2 ms -- the arithmetic was already hidden under
+//    the gather, the hand-off (LDS write, release, poll, acquire, LDS read) is not;
+//  * whole records fetched cooperatively into LDS (global_load_lds_dwordx4, eight lanes per 128-byte record, eight
+//    instructions per 64 candidates): in the micro-benchmark 920-1 000 cycles against 890 for the nine per-lane loads
+//    with one wave per CU -- it only pays at 8+ waves per CU (3 200 against 4 600), where the launches are not bound;
+//  * s_setprio 3 for attempts past 512 steps (the launch ends with its longest plane): urban 10 M 113.0 vs 108.7 ms,
+//    50 M 186.5 vs 181.4 ms.
 // What bounds a step is the length of the wave's dependent instruction chain (pop -> addresses -> gather -> f64 test
 // -> votes -> claims -> push, ~330 instructions at ~9 cycles each for a wave alone on its SIMD), not the memory level.
 constexpr int LBUF = 256;  // LDS ring of pointIdx entries (flushed in bursts of 64)
@@ -2685,7 +2700,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       // is grown again has the time to finish inside the same launch (urban 10 M: +20 %); in a round of a few
       // chained planes (the facade) the re-growth only repeats work the next round does anyway (-23 %).
       const int rml = (ncand >= retry_big_round && !retry_env) ? 0x7fffffff : retry_max_list;
-      const bool grow_v1 = grow_force >= 0 ? grow_force == 0 : !(KC == 16 && ncand < 4096);
+      const bool grow_v1 = grow_force >= 0 ? grow_force == 0 : !(KC == 16 && ncand < 65536);
       if (grow_v1) {
         if (KC == 16)
           grow_spec_kernel<16><<<ncand, 64, lds_pad, st>>>(a, d_cand, ncand, rec, dead, pool, d_out, 512 * n + 4096, rml, d_order);
@@ -3047,7 +3062,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
       BS_HIP(ctx, hipMemcpyAsync(d_cand, hc_sorted.data(), sizeof(unsigned long long) * na, hipMemcpyHostToDevice, st));
     a.F = INF;
     auto grow_n = [&](int off, int cnt, PlaneOut* o) {
-      const bool grow_v1 = grow_force >= 0 ? grow_force == 0 : !(KC == 16 && cnt < 4096);
+      const bool grow_v1 = grow_force >= 0 ? grow_force == 0 : !(KC == 16 && cnt < 65536);
       if (grow_v1) {
         if (KC == 16)
           grow_spec_kernel<16><<<cnt, 64, 0, st>>>(a, d_cand + off, cnt, rec, dead, pool, o, 512 * n + 4096, 0, nullptr);
