@@ -1372,6 +1372,7 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         double mx, my, mz;
         bool geo, valid;
         int ngv;
+        int killed_v, vt;  // (in flight until rows_wait)
         bool lost_any;  // killed, or a claim of the previous call was lost
         v4i rows[CH];  // the candidate's own neighbour row (it becomes its LIFO entry if it is accepted)
       };
@@ -1391,18 +1392,19 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         // gets an s_waitcnt vmcnt(0) (the wait-count pass merges the back edge's pending events conservatively), and
         // that wait sits right behind the previous step's claim atomics: 600-900 cycles per step.
         // (the killed flag is read by every lane from ONE address, but the compiler cannot know that the lanes agree)
-        int killed_v, vt;
         v4i q0, q1, q2;
         {
           const int32_t* kp = dead + seed;
           const int32_t* vp = pendv ? vptr : dead + seed;
           const int4* r = rec + (int64_t)E.cand_id * Q;
-          asm volatile("global_load_dword %3, %6, off sc1\n\t"
-                       "global_load_dword %4, %7, off sc1\n\t"
-                       "global_load_dwordx4 %0, %5, off\n\t"
+          // what the test needs first, then what only the commit needs: the killed flag, the read-back of the previous
+          // claims and (below) the candidates' rows
+          asm volatile("global_load_dwordx4 %0, %5, off\n\t"
                        "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                       "global_load_dwordx4 %2, %5, off offset:32 sc1"
-                       : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(killed_v), "=&v"(vt)
+                       "global_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
+                       "global_load_dword %3, %6, off sc1\n\t"
+                       "global_load_dword %4, %7, off sc1"
+                       : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(E.killed_v), "=&v"(E.vt)
                        : "v"(r), "v"(kp), "v"(vp)
                        : "memory");
 #pragma unroll
@@ -1430,12 +1432,12 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
         }
         PROBE(1);
         // ---- the ONE wait of the gather (the operands tie every later use of the data behind it) ----
-        // (loads return in issue order: with CH still outstanding the five above have landed; the candidates' own rows
-        // are only needed by the push and keep streaming in under the test: rows_wait() below)
+        // (loads return in issue order: with CH + 2 still outstanding the three record loads have landed; the flags and
+        // the candidates' own rows are only needed by the commit and keep streaming in under the test: rows_wait() below)
         if (CH == 4)
-          asm volatile("s_waitcnt vmcnt(4)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(killed_v), "+v"(vt)::"memory");
+          asm volatile("s_waitcnt vmcnt(6)" : "+v"(q0), "+v"(q1), "+v"(q2)::"memory");
         else
-          asm volatile("s_waitcnt vmcnt(8)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(killed_v), "+v"(vt)::"memory");
+          asm volatile("s_waitcnt vmcnt(10)" : "+v"(q0), "+v"(q1), "+v"(q2)::"memory");
         PROBE(2);
         E.px = q0.x;
         E.py = q0.y;
@@ -1454,8 +1456,6 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
           const bool okd = dist <= a.th, okn = dt >= a.cos_th;      // both chains run side by side
           E.geo = E.valid & act & (E.tg != seed) & okd & okn;       // tg == seed: already labelled by this plane
         }
-        const bool lost = pendv && vt != seed;  // an earlier plane got there first
-        E.lost_any = __builtin_amdgcn_readfirstlane(killed_v) != 0 || ballot64(lost) != 0;
       };
       // The rows of the candidates are still in flight after eval(): EVERY path from eval() on passes through this wait
       // before it reads them, issues another vector-memory instruction, or leaves the step (their destination registers
@@ -1463,11 +1463,14 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
       auto rows_wait = [&](Ev& E) {
         static_assert(CH == 4 || CH == 8, "row chunks");
         if constexpr (CH == 4)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(E.rows[0]), "+v"(E.rows[1]), "+v"(E.rows[2]), "+v"(E.rows[3])::"memory");
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(E.rows[0]), "+v"(E.rows[1]), "+v"(E.rows[2]), "+v"(E.rows[3]), "+v"(E.killed_v), "+v"(E.vt)::"memory");
         else
           asm volatile("s_waitcnt vmcnt(0)"
                        : "+v"(E.rows[0]), "+v"(E.rows[1]), "+v"(E.rows[2]), "+v"(E.rows[3]), "+v"(E.rows[4]), "+v"(E.rows[5]),
-                         "+v"(E.rows[6]), "+v"(E.rows[7])::"memory");
+                         "+v"(E.rows[6]), "+v"(E.rows[7]), "+v"(E.killed_v), "+v"(E.vt)::"memory");
+        const bool lost = pendv && E.vt != seed;  // an earlier plane got there first
+        E.lost_any = __builtin_amdgcn_readfirstlane(E.killed_v) != 0 || ballot64(lost) != 0;
       };
       // ---- expansion of call gstar (:231-255): list ring, deferred state, children onto the LIFO ----
       auto expand = [&](const Ev& E, bool ok, unsigned long long am, int gstar, int cnt) {

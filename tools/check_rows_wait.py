@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Checks the generated ISA of grow_spec2_kernel: between the partial wait of the gather (s_waitcnt vmcnt(CH)) and the
-wait for the candidates' rows (s_waitcnt vmcnt(0)) no instruction may read or write the rows' destination registers --
+"""Checks the generated ISA of grow_spec2_kernel: between the partial wait of the gather (s_waitcnt vmcnt(CH + 2)) and the
+wait for the flags and the candidates' rows (s_waitcnt vmcnt(0)) no instruction may read or write their destination registers --
 the loads are still writing them (csrc/bs_grow_spec.hip, rows_wait).  Usage: check_rows_wait.py [file.s]; without an
 argument the device assembly is produced with hipcc -S (about a minute)."""
 import os
@@ -42,14 +42,17 @@ def check(path):
         en = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
         labels = {m.group(1): i for i in range(st, en) for m in [re.match(r"^(\.LBB\d+_\d+):", lines[i])] if m}
         for i in range(st, en):
-            if "s_waitcnt vmcnt(%d)" % ch not in lines[i]:
+            if "s_waitcnt vmcnt(%d)" % (ch + 2) not in lines[i]:
                 continue
             rows, j = [], i
-            while len(rows) < ch and j > st:  # the ch loads issued last before the wait
+            while len(rows) < ch + 2 and j > st:  # the loads issued last before the wait: two flags, ch row chunks
                 j -= 1
                 m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", lines[j])
                 if m:
                     rows.append((int(m.group(1)), int(m.group(2))))
+                m = re.search(r"global_load_dword v(\d+),", lines[j])
+                if m:
+                    rows.append((int(m.group(1)), int(m.group(1))))
             rowregs = {r for a, b in rows for r in range(a, b + 1)}
             checked += 1
             # walk every path from the wait until an s_waitcnt vmcnt(0)
