@@ -1247,15 +1247,24 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
 //    146.9 ms;
 //  * one combined test per kind of loop exit instead of separate breaks: 145.0 ms (the back edge grew to 570 cycles).
 //  * the plane state on a second wave of the workgroup (128 threads: wave 1 keeps the running sums and publishes
-//    normal and centre through LDS, wave 0 traverses): 143.4 vs 131.2 ms -- the arithmetic was already hidden under
-//    the gather, the hand-off (LDS write, release, poll, acquire, LDS read) is not;
+//    normal and centre through LDS, wave 0 traverses).  With a release/acquire hand-off 143.4 vs 131.2 ms (the
+//    release waits for the claim atomics' round trip); with a fence-free sequence number in LDS (the LDS operations
+//    of a wave are executed in order) and the accepted points posted before the claims: facade 129.3 vs 120.6 ms,
+//    urban 10 M 106.6 vs 111.5 ms.  The stamps say why: the state wave needs 1 270 cycles per expansion and is never
+//    late, but wave 0 now waits 757 instead of 147 cycles for its gather -- on a 128 MB record array the gather
+//    chain (pop 150 + issue 350 + Infinity Cache 850) is what the arithmetic used to hide under, so taking the
+//    arithmetic away buys nothing there, and the posting costs 230 cycles;
 //  * whole records fetched cooperatively into LDS (global_load_lds_dwordx4, eight lanes per 128-byte record, eight
 //    instructions per 64 candidates): in the micro-benchmark 920-1 000 cycles against 890 for the nine per-lane loads
 //    with one wave per CU -- it only pays at 8+ waves per CU (3 200 against 4 600), where the launches are not bound;
 //  * s_setprio 3 for attempts past 512 steps (the launch ends with its longest plane): urban 10 M 113.0 vs 108.7 ms,
 //    50 M 186.5 vs 181.4 ms.
-// What bounds a step is the length of the wave's dependent instruction chain (pop -> addresses -> gather -> f64 test
-// -> votes -> claims -> push, ~330 instructions at ~9 cycles each for a wave alone on its SIMD), not the memory level.
+// What bounds a step (stamps of this engine on facade 1 M, cycles: pop + issue 510, plane state 700 over it, wait 150,
+// test + classification 265, claims 390, list ring 305, push 150, loop control and exits 360 = 2 900) is the wave's own
+// instruction stream -- one wave issues one instruction every ~6 cycles, and every phase consumes what the one before
+// produced -- around a gather chain of ~1 350 cycles that the state arithmetic covers.  Issuing the next gather
+// before this step's claims would overlap the two halves, but the next step's candidates are the neighbours of the
+// points claimed now: the tags they read must already carry the claims, or a point is accepted twice.
 constexpr int LBUF = 256;  // LDS ring of pointIdx entries (flushed in bursts of 64)
 #ifdef BS_PROBE
 // cycle stamps between the phases of a step (developer build: tools/probe_grow2.sh); planes with > 20 000 entries
