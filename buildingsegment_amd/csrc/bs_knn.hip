@@ -232,6 +232,246 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
   }
 }
 
+constexpr int KBUF = 8;  // waiting candidates per thread of knn_fast2_kernel
+
+template <int KC>
+__global__ __launch_bounds__(256) void knn_fast2_kernel(GridDev g, int64_t q_begin, int64_t q_end, int K,
+                                                       int max_nn, double r2, int32_t* __restrict__ neigh,
+                                                       double* __restrict__ normals,
+                                                       int32_t* __restrict__ fb_list,
+                                                       int32_t* __restrict__ fb_count, uint64_t cert_r2,
+                                                       unsigned long long* __restrict__ uncert,
+                                                       int32_t* __restrict__ npos, unsigned long long* __restrict__ tie_rows)
+{
+  const int64_t s = xcd_logical_block() * (int64_t)blockDim.x + threadIdx.x;
+  if (s >= g.n)
+    return;
+  const int32_t loc = g.slocal[s];
+  if (loc < q_begin || loc >= q_end)
+    return;
+  // runner-up: the smallest key that is NOT in the list (only needed when the list fills every slot, K == KC):
+  // the (K+1)-th neighbour decides whether the list's boundary is an equal-d^2 tie
+  uint64_t runner = ~0ull;
+  const int4 P = g.spts[s];
+  const int q[3] = {P.x, P.y, P.z};
+  const int ci[3] = {(int)((uint32_t)(P.x - g.mn[0]) / (uint32_t)g.cell),
+                     (int)((uint32_t)(P.y - g.mn[1]) / (uint32_t)g.cell),
+                     (int)((uint32_t)(P.z - g.mn[2]) / (uint32_t)g.cell)};
+  // candidates that beat the list's last entry wait in LDS (KBUF per thread, slot-major: conflict-free) ...
+  __shared__ uint32_t blo[KBUF][256], bhi[KBUF][256];
+  __shared__ int bps[KBUF][256];
+  int nbuf = 0;
+  uint64_t best[KC];
+  // cell-sorted POSITION of every kept candidate, carried through the insertion network as a payload:
+  // the region grower addresses points by position (bs_grow_spec.hip) and would otherwise have to look
+  // every neighbour up by its index -- one random HBM access per edge
+  int bpos[KC];
+#pragma unroll
+  for (int j = 0; j < KC; j++) {
+    best[j] = ~0ull;
+    bpos[j] = 0;
+  }
+  Moments m = {};
+  bool done = false;
+  // ... until one thread of the wave has KBUF of them: then every thread sorts its waiting candidates (19
+  // compare-exchanges) and merges them into its list (reverse, lower half, bitonic merge: KBUF + KC/2 log2 KC more).
+  // The per-candidate insertion network this replaces (KC compare-exchanges, run by the WHOLE wave whenever ONE of its
+  // 64 queries admits a candidate -- nearly always) cost 3x as many instructions per query.
+  auto flush = [&]() {
+    uint64_t bk[KBUF];
+    int bp[KBUF];
+#pragma unroll
+    for (int i = 0; i < KBUF; i++) {
+      const bool have = i < nbuf;
+      bk[i] = have ? (((uint64_t)bhi[i][threadIdx.x] << 32) | blo[i][threadIdx.x]) : ~0ull;
+      bp[i] = have ? bps[i][threadIdx.x] : 0;
+    }
+    nbuf = 0;
+#define BS_CE(ka, pa, kb, pb)            \
+  do {                                   \
+    const bool sw_ = (kb) < (ka);        \
+    const uint64_t tk_ = (ka);           \
+    const int tp_ = (pa);                \
+    (ka) = sw_ ? (kb) : (ka);            \
+    (pa) = sw_ ? (pb) : (pa);            \
+    (kb) = sw_ ? tk_ : (kb);             \
+    (pb) = sw_ ? tp_ : (pb);             \
+  } while (0)
+    // optimal 8-input sorting network
+    constexpr int net[19][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {0, 2}, {1, 3}, {4, 6}, {5, 7}, {1, 2}, {5, 6},
+                                {0, 4}, {3, 7}, {1, 5}, {2, 6}, {1, 4}, {3, 6}, {2, 4}, {3, 5}, {3, 4}};
+#pragma unroll
+    for (int c = 0; c < 19; c++)
+      BS_CE(bk[net[c][0]], bp[net[c][0]], bk[net[c][1]], bp[net[c][1]]);
+    // list (ascending) against the waiting candidates (descending): the lower of each pair stays -- a bitonic sequence
+    // of the KC smallest; the higher ones are out for good, the smallest of them is the runner-up so far
+#pragma unroll
+    for (int i = 0; i < KBUF; i++)
+      BS_CE(best[KC - KBUF + i], bpos[KC - KBUF + i], bk[KBUF - 1 - i], bp[KBUF - 1 - i]);
+#pragma unroll
+    for (int i = 0; i < KBUF; i++)
+      runner = bk[i] < runner ? bk[i] : runner;
+#pragma unroll
+    for (int d = KC / 2; d >= 1; d >>= 1) {
+#pragma unroll
+      for (int i = 0; i < KC; i++)
+        if ((i & d) == 0)
+          BS_CE(best[i], bpos[i], best[i + d], bpos[i + d]);
+    }
+#undef BS_CE
+  };
+  for (int rho = 0; rho <= BS_FAST_RINGS && !done; rho++) {
+    for (int dz = -rho; dz <= rho; dz++) {
+      const int cz = ci[2] + dz;
+      if (cz < 0 || cz >= g.dim[2])
+        continue;
+      for (int dy = -rho; dy <= rho; dy++) {
+        const int cy = ci[1] + dy;
+        if (cy < 0 || cy >= g.dim[1])
+          continue;
+        const bool face = (dz == -rho || dz == rho || dy == -rho || dy == rho);
+        const int step = face ? 1 : (rho > 0 ? 2 * rho : 1);
+        // The kernel is bound by latency, not by arithmetic (108-128 registers: 4 waves per SIMD, and every hash
+        // probe and every candidate used to be ONE load followed by its use): the first probes of up to three cells
+        // of a row are issued together, and the candidates of a cell are fetched four at a time.
+        for (int dx0 = -rho; dx0 <= rho; dx0 += 3 * step) {
+          int4 raw[3];
+          uint64_t ck[3];
+          uint32_t hh[3];
+          bool want[3];
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            const int dx = dx0 + u * step;
+            const int cx = ci[0] + dx;
+            want[u] = dx <= rho && cx >= 0 && cx < g.dim[0];
+            ck[u] = pack_cell((uint32_t)(want[u] ? cx : ci[0]), (uint32_t)cy, (uint32_t)cz);
+            hh[u] = hash_cell(ck[u]) & g.hmask;
+            raw[u] = *reinterpret_cast<const int4*>(&g.table[hh[u]]);
+          }
+          int cs3[3], ce3[3];
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            cs3[u] = 0;
+            ce3[u] = 0;
+            if (!want[u])
+              continue;
+            for (;;) {  // (linear probing: the first probe is nearly always the cell or an empty slot)
+              const uint64_t ek = (uint64_t)(uint32_t)raw[u].x | ((uint64_t)(uint32_t)raw[u].y << 32);
+              if (ek == ck[u]) {
+                cs3[u] = raw[u].z;
+                ce3[u] = raw[u].w;
+                break;
+              }
+              if (ek == ~0ull)
+                break;
+              hh[u] = (hh[u] + 1) & g.hmask;
+              raw[u] = *reinterpret_cast<const int4*>(&g.table[hh[u]]);
+            }
+          }
+          // ONE copy of the candidate loop (and of the merge in it: 560 instructions) for the three cells
+#pragma unroll 1
+          for (int u = 0; u < 3; u++) {
+            const int cs = u == 0 ? cs3[0] : (u == 1 ? cs3[1] : cs3[2]);
+            const int ce = u == 0 ? ce3[0] : (u == 1 ? ce3[1] : ce3[2]);
+            for (int t0 = cs; t0 < ce; t0 += 4) {
+              int4 cc[4];
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+                cc[v] = g.spts[t0 + v < ce ? t0 + v : ce - 1];
+#pragma unroll
+              for (int v = 0; v < 4; v++) {
+                const int t = t0 + v;
+                const int4 c = cc[v];
+                const int ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
+                const uint32_t d2 = (uint32_t)(ex * ex) + (uint32_t)(ey * ey) + (uint32_t)(ez * ez);
+                const uint64_t key = ((uint64_t)d2 << 32) | (uint32_t)c.w;
+                const bool real = t < ce;  // (the last batch of a cell repeats its last point)
+                if (real && key < best[KC - 1]) {  // (the list's last entry as of the last merge: never below the true bound)
+                  blo[nbuf][threadIdx.x] = (uint32_t)key;
+                  bhi[nbuf][threadIdx.x] = d2;
+                  bps[nbuf][threadIdx.x] = t;
+                  nbuf++;
+                } else if (real) {
+                  runner = key < runner ? key : runner;  // not admitted
+                }
+                if (__ballot(nbuf == KBUF))
+                  flush();
+                if (real && (double)d2 < r2)
+                  moments_add(m, c.x, c.y, c.z);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (__ballot(nbuf > 0))
+      flush();
+    uint64_t R2;
+    const bool bounded = guaranteed_radius(g, q, ci, rho, R2);
+    if (!bounded) {
+      done = true;
+    } else {
+      uint64_t kth = ~0ull;
+#pragma unroll
+      for (int j = 0; j < KC; j++)
+        kth = (j == K - 1) ? best[j] : kth;
+      const bool knn_ok = kth != ~0ull && (kth >> 32) < R2;
+      const bool nrm_ok = (double)R2 >= r2;
+      done = knn_ok && nrm_ok;
+    }
+  }
+  uint64_t kth_final = ~0ull;
+#pragma unroll
+  for (int j = 0; j < KC; j++)
+    kth_final = (j == K - 1) ? best[j] : kth_final;
+  if (!done || m.n > max_nn || kth_final == ~0ull) {
+    const int slot = atomicAdd(fb_count, 1);
+    fb_list[slot] = (int32_t)s;
+    return;
+  }
+  int32_t* row = neigh + (int64_t)(loc - q_begin) * K;
+#pragma unroll
+  for (int j = 0; j < KC; j++)
+    if (j < K)
+      row[j] = (int32_t)(uint32_t)best[j];
+  if (npos) {  // rows in POSITION order: coalesced
+    int32_t* prow = npos + s * K;
+#pragma unroll
+    for (int j = 0; j < KC; j++)
+      if (j < K)
+        prow[j] = bpos[j];
+  }
+  if (normals) {
+    const V3 nv = normal_from_moments(m);
+    double* o = normals + 3 * (int64_t)(loc - q_begin);
+    o[0] = nv.x;
+    o[1] = nv.y;
+    o[2] = nv.z;
+    if (npos) {  // ... and once more in position order, for the grower's records
+      double* po = pnorm_of(npos, g.n, K) + 3 * s;
+      po[0] = nv.x;
+      po[1] = nv.y;
+      po[2] = nv.z;
+    }
+  }
+  if (cert_r2 && (kth_final >> 32) >= cert_r2)
+    atomicAdd(uncert, 1ull);
+  if (tie_rows) {
+    // tie exposure: an equal-d^2 pair inside the k-list or at its boundary -- the only rows where
+    // the reference's kd-tree traversal order can differ from this build's canonical (d^2, index) order
+    bool tie = false;
+    uint64_t next = runner;  // the (K+1)-th neighbour: slot K of the register list when K < KC
+#pragma unroll
+    for (int j = 0; j + 1 < KC; j++) {
+      tie = tie || (j + 1 < K && (best[j] >> 32) == (best[j + 1] >> 32));
+      next = (j + 1 == K) ? best[j + 1] : next;
+    }
+    tie = tie || (next != ~0ull && (next >> 32) == (kth_final >> 32));
+    if (tie)
+      atomicAdd(tie_rows, 1ull);
+  }
+}
+
 // ---- general exact path: explicit sorted lists in scratch -------------------
 
 __device__ inline bool cand_less(uint64_t d2a, int32_t ia, uint64_t d2b, int32_t ib)
@@ -440,7 +680,20 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
     // (an LDS-staged tile variant -- the 27-cell neighbourhood of 256 consecutive queries staged once per workgroup --
     // was measured slower on MI355X, 1 M points: 1.00 vs 0.58 ms, 50 M: 51.7 vs 24.3 ms, and is retired: the cell-sorted
     // order already makes L1 / L2 serve the candidates, while staging costs LDS atomics, three barriers and occupancy)
-    if (p.k <= 16)
+    // knn_fast2_kernel (waiting candidates merged eight at a time, probes and candidates fetched in batches) against
+    // knn_fast_kernel (insertion network per candidate, one load per use), MI355X: urban 10 M 9.7 vs 13.6 ms,
+    // uniform 10 M 16.0 vs 18.1 ms, urban 50 M 27.4-28.1 vs 28.8-29.4 ms.  Counters at 50 M (rocprofv3 --pmc): 11.9 k
+    // instead of 16.0 k vector instructions per wave, but 135 instead of 108 registers (3 instead of 4 waves per
+    // SIMD) -- capped to 128 registers the spills (140 bytes of scratch) cost more than the fourth wave brings
+    // (66 ms).  BS_KNN_BUFFERED=0 selects the first kernel.
+    const bool buffered = getenv("BS_KNN_BUFFERED") ? atoi(getenv("BS_KNN_BUFFERED")) != 0 : true;
+    if (buffered && p.k <= 16)
+      knn_fast2_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                   fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
+    else if (buffered)
+      knn_fast2_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                   fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
+    else if (p.k <= 16)
       knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
                                                   fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
     else
