@@ -173,7 +173,9 @@ inline int grid_blocks(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 }  // namespace
 
-// Occupied-cell count at a trial cell size (keys only).
+// Occupied-cell count at a trial cell size (keys only).  (Counting by insertion into an open-addressing table instead
+// of sorting was measured: the points arrive in the caller's order, 50 M random probes into a 1 GB table take 4.5 ms
+// against 2.7 ms for the radix sort -- grid stage 19.7 instead of 11.0 ms.)
 static int count_cells(bs_ctx* ctx, const int32_t* d_xyz, int64_t n, const int mn[3], int cell,
                        int64_t* ncell)
 {

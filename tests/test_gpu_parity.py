@@ -313,10 +313,10 @@ def test_regression_fuzz_7_106_unsettled_claims(gpu_ctx, oracle):
         assert [len(q.pointIdx) for q in planes] == np.diff(opl["offset"]).tolist()
 
 
-def test_lds_tiled_knn_variant_is_bit_identical(gpu_ctx, oracle, monkeypatch):
-    """knn_tile_kernel (LDS-staged patches, opt-in because it measured slower) must
+def test_first_knn_kernel_is_bit_identical(gpu_ctx, oracle, monkeypatch):
+    """BS_KNN_BUFFERED=0 selects the first fast kernel (insertion network per candidate, kept for A/B runs): it must
     produce exactly what the default kernel and the oracle produce."""
-    monkeypatch.setenv("BS_KNN_TILED", "1")
+    monkeypatch.setenv("BS_KNN_BUFFERED", "0")
     for xyz, k in ((synth.plane_cube()[:60000].copy(), 15), (synth.uniform(40000, seed=21), 32),
                    (synth.urban(120_000, seed=8), 16)):
         _check_knn_normals(gpu_ctx, oracle, xyz, k)
