@@ -199,7 +199,9 @@ constexpr int GW_WIN = 256 + 2 * GW_PAD;
 // window (nearly all of them: neighbours in space are neighbours in Morton position) costs an LDS read, the
 // rare one outside a global gather.  Before, every one of the k-1 neighbour tests fetched three 16-byte pieces
 // of a 128-byte record through L2 -- 1.6 KB of fabric traffic per point.
-__global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4* __restrict__ rec, int quads,
+// (rows / row_stride: the neighbour rows in position space -- the kNN kernels' compact copy (stride K: 64 bytes per
+// point) in the fused pipeline, the second half of the 128-byte records otherwise)
+__global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int32_t* __restrict__ rows, int row_stride,
                                                           const int4* __restrict__ geo, uint32_t* __restrict__ hmask,
                                                           int32_t* __restrict__ rcnt, uint32_t* __restrict__ lmask)
 {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
     const double cnx = __hiloint2double(s1.y, s1.x), cny = __hiloint2double(s1.w, s1.z),
                  cnz = __hiloint2double(s2.y, s2.x);
     const int ccx = s0.x, ccy = s0.y, ccz = s0.z;
-    const int32_t* row = reinterpret_cast<const int32_t*>(rec + i * quads + 4);
+    const int32_t* row = rows + i * row_stride;
     uint32_t m = 0, lm = 0;  // lm: bit t-1 set when this point precedes neighbour t in the original order
     for (int t = 1; t < a.K; t++) {
       const int32_t c = row[t];
@@ -277,8 +279,8 @@ __global__ __launch_bounds__(256) void static_mask_kernel(SpecArgs a, const int4
 // points until nothing flips.  Dependencies only run from lower to higher
 // indices, so the iteration settles bottom-up to the unique fixed point; work is
 // proportional to what actually changes, not to n.
-__global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int4* __restrict__ rec,
-                                                       int quads, int64_t n, unsigned long long* __restrict__ rcur,
+__global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restrict__ hmask, const int32_t* __restrict__ rows,
+                                                       int row_stride, int64_t n, unsigned long long* __restrict__ rcur,
                                                        int32_t* __restrict__ radj, const uint32_t* __restrict__ lmask)
 {
   // same window as static_mask_kernel: count per target in LDS, reserve ONE range per (workgroup, target)
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(const uint32_t* __restric
   __syncthreads();
   const uint32_t m0 = i < n ? hmask[i] : 0u;
   const uint32_t lm0 = i < n ? lmask[i] : 0u;  // an entry of R(c) carries LOWER_BIT when its source precedes c in the original order
-  const int32_t* row = reinterpret_cast<const int32_t*>(rec + (i < n ? i : 0) * quads + 4);
+  const int32_t* row = rows + (i < n ? i : 0) * row_stride;
   for (uint32_t m = m0; m;) {
     const int t = __ffs(m) - 1;
     m &= m - 1;
@@ -2454,7 +2456,9 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   // entries (roff[n] = total), then the fill
   BS_HIP(ctx, hipMemsetAsync(rpos, 0, sizeof(int32_t) * (n + 1), st));
   uint32_t* lmask = reinterpret_cast<uint32_t*>(vmark);  // (free until the validation marks are cleared after the fill)
-  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, rec, quads, gs, hmask, rpos, lmask);
+  const int32_t* rows = npos ? npos : reinterpret_cast<const int32_t*>(rec) + 16;
+  const int row_stride = npos ? K : quads * 4;
+  static_mask_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(a, rows, row_stride, gs, hmask, rpos, lmask);
   {
     hipcub::TransformInputIterator<int64_t, ToI64, const int32_t*> in(rpos, ToI64());
     size_t tb = 0;
@@ -2464,7 +2468,7 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
   }
   unsigned long long* rcur = cand_raw;
   BS_HIP(ctx, hipMemcpyAsync(rcur, roff, sizeof(int64_t) * n, hipMemcpyDeviceToDevice, st));
-  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rec, quads, n, rcur, radj, lmask);
+  rev_fill_kernel<<<xcd_grid(nblk(n, 256)), 256, 0, st>>>(hmask, rows, row_stride, n, rcur, radj, lmask);
   // initial state: no plane; the first owner fixed point is computed by decided states (see
   // decide_pass_kernel), after which nothing is dirty
   fill_i32_kernel<<<nblk(n, 256), 256, 0, st>>>(base, n, INF);
