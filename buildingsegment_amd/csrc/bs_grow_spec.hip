@@ -657,14 +657,18 @@ __global__ void invert_order_kernel(const int32_t* __restrict__ order, int64_t n
 // both null: identity).  The neighbour row is translated to positions here -- the one pass of the
 // stage that has to look things up by original index.
 template <int KC>
-__global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ order, const int32_t* __restrict__ pos,
+__global__ __launch_bounds__(256) void build_records_kernel(SpecArgs a, const int32_t* __restrict__ order, const int32_t* __restrict__ pos,
                                      const int32_t* __restrict__ npos, int4* __restrict__ rec, int32_t* __restrict__ prio,
                                      int4* __restrict__ geo, const int4* __restrict__ spts, const double* __restrict__ pnorm)
 {
-  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (s >= a.n)
-    return;
   constexpr int Q = RecLayout<KC>::QUADS;
+  // Records (128 B) and geometry (48 B) are put together in LDS and leave in whole cache lines: a thread storing its own
+  // record issues eight 16-byte stores 128 bytes apart from its neighbours' (2.4 TB/s of mostly partial-line writes)
+  __shared__ int4 srec[256 * Q];
+  __shared__ int4 sgeo[256 * 3];
+  const int64_t b0 = blockIdx.x * (int64_t)blockDim.x;
+  const int64_t s = b0 + threadIdx.x;
+  if (s < a.n) {
   // fused pipeline: coordinates + original index from the grid's cell-sorted copy, normals from the kNN kernels'
   // position-ordered copy -- everything streams; otherwise both are gathered by original index
   int64_t i;
@@ -681,7 +685,7 @@ __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ ord
     py = a.xyz[3 * i + 1];
     pz = a.xyz[3 * i + 2];
   }
-  int4* r = rec + s * Q;
+  int4* r = srec + threadIdx.x * Q;
   const double* nsrc = pnorm ? pnorm + 3 * s : a.normals + 3 * i;
   const double nx = nsrc[0], ny = nsrc[1], nz = nsrc[2];
   r[0] = make_int4(px, py, pz, INF);
@@ -690,9 +694,9 @@ __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ ord
   r[3] = make_int4(0, 0, 0, 0);
   // compact geometry (48 B per position) for the LDS tiles of static_mask_kernel; its spare word carries the
   // original index, so that the kernel can also tell which neighbours a point precedes
-  geo[3 * s] = make_int4(px, py, pz, (int32_t)i);
-  geo[3 * s + 1] = r[1];
-  geo[3 * s + 2] = r[2];
+  sgeo[3 * threadIdx.x] = make_int4(px, py, pz, (int32_t)i);
+  sgeo[3 * threadIdx.x + 1] = r[1];
+  sgeo[3 * threadIdx.x + 2] = r[2];
   prio[s] = (int32_t)i;
   int row[KC];
 #pragma unroll
@@ -726,6 +730,15 @@ __global__ void build_records_kernel(SpecArgs a, const int32_t* __restrict__ ord
 #pragma unroll
   for (int j = 0; j < KC; j += 4)
     r[4 + j / 4] = make_int4(row[j], row[j + 1], row[j + 2], row[j + 3]);
+  }  // s < n
+  __syncthreads();
+  const int64_t nv = a.n - b0 < 256 ? a.n - b0 : 256;
+  int4* rout = rec + b0 * Q;
+  for (int t = threadIdx.x; t < nv * Q; t += 256)
+    rout[t] = srec[t];
+  int4* gout = geo + 3 * b0;
+  for (int t = threadIdx.x; t < nv * 3; t += 256)
+    gout[t] = sgeo[t];
 }
 
 // per round: owner snapshot in, claims cleared
