@@ -3,4 +3,4 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/buildingsegment_amd/csrc
 exec /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -I$R/include -I$C $C/bs_capi.hip $C/bs_grid.hip $C/bs_knn.hip $C/bs_grow.hip "$1" $C/bs_prepost.hip $C/bs_raster.hip -o "$2"
+  -I$R/include -I$C $C/bs_capi.hip $C/bs_grid.hip $C/bs_knn.hip $C/bs_grow.hip "$1" $C/bs_prepost.hip $C/bs_raster.hip $C/bs_shard.hip $C/bs_sharded.hip -ldl -o "$2"
