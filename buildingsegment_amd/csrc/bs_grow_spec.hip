@@ -391,6 +391,9 @@ __global__ void pull_pass_kernel(int64_t n, int K, int sub, const uint32_t* __re
           v = pj[i] < v ? pj[i] : v;
       }
     }
+    // (the makers' original indices stored beside the reverse-list entries, instead of prio[j] for the occurring ones:
+    // measured at 50 M -- owner passes 25.9 vs 25.6 ms per pass, rev_fill 8.7 vs 5.7 ms, decide_finish 3.1 vs 2.7 ms:
+    // few sources of a list occur, so the look-up it saves is rare and the extra stream is not)
     omega[c] = v;
     reinterpret_cast<int32_t*>(rec + c * quads)[3] = v;  // the growth kernel reads the owner from the record
     const uint32_t m0 = hmask[c];
