@@ -639,6 +639,165 @@ __global__ __launch_bounds__(64) void knn_general_kernel(GridDev g, int64_t q_be
   }
 }
 
+// ---- general exact path by the WAVE ------------------------------------------------------------------------------
+// One wave per work-listed query (a query of the fast kernel that holds more than max_nn points inside the radius --
+// the hybrid search keeps the nearest max_nn, which needs an order -- or was not certified within its rings).  The
+// lanes share the cells of a ring, every point they see goes into an LDS buffer, the buffer is sorted by (d^2, index)
+// with a bitonic network after each ring: the k-list is its first K entries, the hybrid list the entries with
+// d^2 < r^2 among its first max_nn, the runner-up entry K.  A query whose candidates do not fit, or that is still
+// uncertified after BS_GENERAL_RINGS rings, goes to the one-thread kernel above (second work list).  A thread of
+// that kernel took milliseconds per query (two insertion sorts in scratch memory over a few hundred candidates):
+// 0.4 % of a uniform cloud's queries were 40 % of its stage-2 time.
+constexpr int GCAP = 2048;  // candidates per query in LDS (32 KB)
+
+__global__ __launch_bounds__(64) void knn_general_wave_kernel(GridDev g, int64_t q_begin, int K, int max_nn, double r2,
+                                                              int32_t* __restrict__ neigh, double* __restrict__ normals,
+                                                              const int32_t* __restrict__ fb_list,
+                                                              const int32_t* __restrict__ fb_count, uint64_t cert_r2,
+                                                              unsigned long long* __restrict__ uncert,
+                                                              int32_t* __restrict__ npos, unsigned long long* __restrict__ tie_rows,
+                                                              int32_t* __restrict__ fb2_list, int32_t* __restrict__ fb2_count)
+{
+  __shared__ uint64_t bd2[GCAP];
+  __shared__ int32_t bidx[GCAP], bpos[GCAP];
+  __shared__ int cxyz[64][3];
+  const int lane = threadIdx.x;
+  const int total = *fb_count;
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int32_t s = fb_list[w];
+    const int32_t loc = g.slocal[s];
+    const int4 P = g.spts[s];
+    const int q[3] = {P.x, P.y, P.z};
+    const int ci[3] = {(int)((uint32_t)(P.x - g.mn[0]) / (uint32_t)g.cell),
+                       (int)((uint32_t)(P.y - g.mn[1]) / (uint32_t)g.cell),
+                       (int)((uint32_t)(P.z - g.mn[2]) / (uint32_t)g.cell)};
+    int count = 0;
+    bool done = false, overflow = false;
+    for (int rho = 0; rho <= BS_GENERAL_RINGS && !done && !overflow; rho++) {
+      const int side = 2 * rho + 1, ncell = side * side * side;
+      for (int c0 = 0; c0 < ncell; c0 += 64) {  // (uniform trip count)
+        const int c = c0 + lane;
+        const int dz = c / (side * side) - rho, dy = (c / side) % side - rho, dx = c % side - rho;
+        const int cx = ci[0] + dx, cy = ci[1] + dy, cz = ci[2] + dz;
+        const int cheb = max(max(abs(dx), abs(dy)), abs(dz));
+        int cs = 0, ce = 0;
+        if (c < ncell && cheb == rho && cx >= 0 && cx < g.dim[0] && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2]) {
+          if (!cell_lookup(g, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, cs, ce))
+            cs = ce = 0;
+        }
+        for (int t = cs; __ballot(t < ce) != 0; t++) {
+          const bool have = t < ce;
+          const unsigned long long m = __ballot(have);
+          const int slot = count + __popcll(m & ((1ull << lane) - 1ull));
+          if (have && slot < GCAP) {
+            const int4 p = g.spts[t];
+            const int64_t ex = (int64_t)p.x - q[0], ey = (int64_t)p.y - q[1], ez = (int64_t)p.z - q[2];
+            bd2[slot] = (uint64_t)(ex * ex) + (uint64_t)(ey * ey) + (uint64_t)(ez * ez);
+            bidx[slot] = p.w;
+            bpos[slot] = t;
+          }
+          count += __popcll(m);
+        }
+      }
+      if (count > GCAP) {
+        overflow = true;
+        break;
+      }
+      // bitonic sort of the buffer (padded to a power of two with +inf) by (d^2, index), ascending
+      int P2 = 64;
+      while (P2 < count)
+        P2 <<= 1;
+      for (int i = count + lane; i < P2; i += 64) {
+        bd2[i] = ~0ull;
+        bidx[i] = 0x7fffffff;
+        bpos[i] = 0;
+      }
+      __syncthreads();
+      for (int k2 = 2; k2 <= P2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+          for (int i = lane; i < P2; i += 64) {
+            const int l = i ^ j;
+            if (l > i) {
+              const uint64_t da = bd2[i], db = bd2[l];
+              const int32_t ia = bidx[i], ib = bidx[l];
+              const bool a_gt_b = da > db || (da == db && ia > ib);
+              const bool up = (i & k2) == 0;
+              if (a_gt_b == up) {
+                bd2[i] = db;
+                bd2[l] = da;
+                bidx[i] = ib;
+                bidx[l] = ia;
+                const int32_t pa = bpos[i];
+                bpos[i] = bpos[l];
+                bpos[l] = pa;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      uint64_t R2;
+      const bool bounded = guaranteed_radius(g, q, ci, rho, R2);
+      if (!bounded)
+        done = true;
+      else
+        done = count >= K && bd2[K - 1] < R2 && (double)R2 >= r2;
+      __syncthreads();
+    }
+    if (overflow || !done || count < K) {  // the one-thread kernel scans on (or the whole cloud)
+      if (lane == 0)
+        fb2_list[atomicAdd(fb2_count, 1)] = s;
+      __syncthreads();
+      continue;
+    }
+    if (lane < K) {
+      neigh[(int64_t)(loc - q_begin) * K + lane] = bidx[lane];
+      if (npos)
+        npos[(int64_t)s * K + lane] = bpos[lane];
+    }
+    if (normals) {
+      // hybrid list: the entries with d^2 < r^2 among the first max_nn (the buffer is sorted by d^2: they are a prefix)
+      const bool in = lane < max_nn && lane < count && (double)bd2[lane] < r2;
+      const int mc = __popcll(__ballot(in));
+      if (in) {
+        const int4 p = g.spts[bpos[lane]];
+        cxyz[lane][0] = p.x;
+        cxyz[lane][1] = p.y;
+        cxyz[lane][2] = p.z;
+      }
+      __syncthreads();
+      if (lane == 0) {
+        Moments m = {};
+        for (int j = 0; j < mc; j++)
+          moments_add(m, cxyz[j][0], cxyz[j][1], cxyz[j][2]);
+        const V3 nv = normal_from_moments(m);
+        double* o = normals + 3 * (int64_t)(loc - q_begin);
+        o[0] = nv.x;
+        o[1] = nv.y;
+        o[2] = nv.z;
+        if (npos) {
+          double* po = pnorm_of(npos, g.n, K) + 3 * (int64_t)s;
+          po[0] = nv.x;
+          po[1] = nv.y;
+          po[2] = nv.z;
+        }
+      }
+    }
+    if (lane == 0) {
+      if (cert_r2 && bd2[K - 1] >= cert_r2)
+        atomicAdd(uncert, 1ull);
+      if (tie_rows) {
+        bool tie = count > K && bd2[K] == bd2[K - 1];
+        for (int j = 0; j + 1 < K; j++)
+          tie = tie || bd2[j] == bd2[j + 1];
+        if (tie)
+          atomicAdd(tie_rows, 1ull);
+      }
+    }
+    __syncthreads();  // (the buffers are reused by the next query)
+  }
+}
+
 __global__ void mark_all_kernel(GridDev g, int64_t q_begin, int64_t q_end, int32_t* fb_list,
                                 int32_t* fb_count)
 {
@@ -658,9 +817,11 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
 {
   hipStream_t st = ctx->stream;
   const int64_t n = g.n;
-  BS_HIP(ctx, ctx->fb_list.reserve(sizeof(int32_t) * (n + 16)));
+  BS_HIP(ctx, ctx->fb_list.reserve(sizeof(int32_t) * (2 * n + 32)));
   int32_t* fb_list = ctx->fb_list.as<int32_t>() + 16;
   int32_t* fb_count = ctx->fb_list.as<int32_t>();
+  int32_t* fb2_list = fb_list + n + 16;  // queries the wave kernel hands on to the one-thread kernel
+  int32_t* fb2_count = ctx->fb_list.as<int32_t>() + 2;
   unsigned long long* uncert = (unsigned long long*)(ctx->fb_list.as<int32_t>() + 4);
   unsigned long long* tie_rows = (unsigned long long*)(ctx->fb_list.as<int32_t>() + 8);
   BS_HIP(ctx, hipMemsetAsync(ctx->fb_list.p, 0, 64, st));
@@ -702,8 +863,15 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
   } else {
     mark_all_kernel<<<blocks, 256, 0, st>>>(g, q_begin, q_end, fb_list, fb_count);
   }
-  knn_general_kernel<<<1024, 64, 0, st>>>(g, q_begin, p.k, p.max_nn, r2, d_neigh, d_normals, fb_list,
-                                          fb_count, cert_r2, uncert, d_npos, tie_rows);
+  if (getenv("BS_KNN_GENERAL_THREAD")) {  // developer A/B switch: the one-thread kernel for the whole work list
+    knn_general_kernel<<<1024, 64, 0, st>>>(g, q_begin, p.k, p.max_nn, r2, d_neigh, d_normals, fb_list, fb_count, cert_r2,
+                                            uncert, d_npos, tie_rows);
+  } else {
+    knn_general_wave_kernel<<<8192, 64, 0, st>>>(g, q_begin, p.k, p.max_nn, r2, d_neigh, d_normals, fb_list, fb_count, cert_r2,
+                                                 uncert, d_npos, tie_rows, fb2_list, fb2_count);
+    knn_general_kernel<<<1024, 64, 0, st>>>(g, q_begin, p.k, p.max_nn, r2, d_neigh, d_normals, fb2_list, fb2_count, cert_r2,
+                                            uncert, d_npos, tie_rows);
+  }
   BS_HIP(ctx, hipGetLastError());
   // bookkeeping read-back (also the point where kernel faults surface)
   int32_t hb[4];

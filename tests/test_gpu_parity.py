@@ -322,6 +322,29 @@ def test_first_knn_kernel_is_bit_identical(gpu_ctx, oracle, monkeypatch):
         _check_knn_normals(gpu_ctx, oracle, xyz, k)
 
 
+def test_general_knn_by_the_wave_and_by_the_thread_agree(gpu_ctx, oracle, monkeypatch):
+    """Work-listed queries (more than max_nn points inside the radius, or uncertified within the fast kernel's rings) go to
+    knn_general_wave_kernel and from there -- buffer overflow, still uncertified -- to the one-thread kernel.  Dense
+    blobs (max_nn 3..50 inside a radius that holds hundreds), a sparse cloud whose rings run out (full scan) and
+    BS_KNN_GENERAL_THREAD=1 (the one-thread kernel alone) must all equal the oracle, with the same work list."""
+    rng = np.random.default_rng(77)
+    dense = rng.integers(0, 600, (30000, 3)).astype(np.int32)  # ~580 points inside r = 100: every query is work-listed
+    lattice = (rng.integers(0, 12, (20000, 3)) * 40).astype(np.int32)  # duplicates and exact ties, > GCAP candidates per ring
+    sparse = np.concatenate([rng.integers(0, 2000, (3000, 3)), rng.integers(0, 2000, (40, 3)) + 400000]).astype(np.int32)
+    counts = {}
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("BS_KNN_GENERAL_THREAD", env)
+        else:
+            monkeypatch.delenv("BS_KNN_GENERAL_THREAD", raising=False)
+        for name, xyz, k, kw in (("dense", dense, 16, {}), ("dense_small_m", dense, 8, {"max_nn": 5}), ("lattice", lattice, 32, {}),
+                                 ("sparse", sparse, 15, {}), ("uniform", synth.uniform(60000, seed=5), 16, {})):
+            _check_knn_normals(gpu_ctx, oracle, xyz, k, **kw)
+            counts.setdefault(name, set()).add(gpu_ctx.timings()["n_fallback_queries"])
+    assert all(len(v) == 1 for v in counts.values()), counts
+    assert min(counts["dense"]) > 20000 and min(counts["sparse"]) > 0
+
+
 @pytest.mark.gpu
 def test_center_div_device_exact(gpu_ctx):
     """csrc/bs_centerdiv.h on the device (hardware reciprocal seed + one Newton
