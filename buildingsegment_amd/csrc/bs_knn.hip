@@ -232,10 +232,20 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
   }
 }
 
+// (the <16, REL32> instance is held to 128 registers, 4 waves per SIMD, at the price of 48 bytes of scratch: uniform 10 M
+// 10.8 against 11.5 ms, urban 50 M 27.7 against 27.3 ms; -DBS_KNN_CAP4=0 builds it uncapped)
+#ifndef BS_KNN_CAP4
+#define BS_KNN_CAP4 1
+#endif
 constexpr int KBUF = 8;  // waiting candidates per thread of knn_fast2_kernel
 
-template <int KC>
-__global__ __launch_bounds__(256) void knn_fast2_kernel(GridDev g, int64_t q_begin, int64_t q_end, int K,
+// REL32: the moment sums of the d^2 < r^2 ball are kept RELATIVE to the query in 32-bit registers (r <= 181 mm: every
+// product is below 2^15, a ball the fast path accepts holds at most max_nn <= 64 points) and turned into the absolute
+// 64-bit sums at the end -- exactly: sum x = n q + sum e, sum x^2 = n q^2 + 2 q sum e + sum e^2, sum xy = n qx qy +
+// qx sum ey + qy sum ex + sum ex ey.  Ten registers instead of nineteen and 24-bit multiplies instead of 64-bit
+// multiply-adds: the kernel drops below 128 registers (4 waves per SIMD instead of 3).
+template <int KC, bool REL32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KC == 16 && REL32 && BS_KNN_CAP4 ? 4 : 2))) void knn_fast2_kernel(GridDev g, int64_t q_begin, int64_t q_end, int K,
                                                        int max_nn, double r2, int32_t* __restrict__ neigh,
                                                        double* __restrict__ normals,
                                                        int32_t* __restrict__ fb_list,
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(256) void knn_fast2_kernel(GridDev g, int64_t q_beg
     bpos[j] = 0;
   }
   Moments m = {};
+  int rsx = 0, rsy = 0, rsz = 0, rsxx = 0, rsyy = 0, rszz = 0, rsxy = 0, rsxz = 0, rsyz = 0, rn = 0;
   bool done = false;
   // ... until one thread of the wave has KBUF of them: then every thread sorts its waiting candidates (19
   // compare-exchanges) and merges them into its list (reverse, lower half, bitonic merge: KBUF + KC/2 log2 KC more).
@@ -396,8 +407,22 @@ __global__ __launch_bounds__(256) void knn_fast2_kernel(GridDev g, int64_t q_beg
                 }
                 if (__ballot(nbuf == KBUF))
                   flush();
-                if (real && (double)d2 < r2)
-                  moments_add(m, c.x, c.y, c.z);
+                if (real && (double)d2 < r2) {
+                  if constexpr (REL32) {
+                    rsx += ex;
+                    rsy += ey;
+                    rsz += ez;
+                    rsxx += __mul24(ex, ex);
+                    rsyy += __mul24(ey, ey);
+                    rszz += __mul24(ez, ez);
+                    rsxy += __mul24(ex, ey);
+                    rsxz += __mul24(ex, ez);
+                    rsyz += __mul24(ey, ez);
+                    rn += 1;
+                  } else {
+                    moments_add(m, c.x, c.y, c.z);
+                  }
+                }
               }
             }
           }
@@ -424,6 +449,19 @@ __global__ __launch_bounds__(256) void knn_fast2_kernel(GridDev g, int64_t q_beg
 #pragma unroll
   for (int j = 0; j < KC; j++)
     kth_final = (j == K - 1) ? best[j] : kth_final;
+  if constexpr (REL32) {
+    const int64_t n64 = rn, qx = q[0], qy = q[1], qz = q[2];
+    m.n = rn;
+    m.sx = n64 * qx + rsx;
+    m.sy = n64 * qy + rsy;
+    m.sz = n64 * qz + rsz;
+    m.sxx = (uint64_t)(n64 * qx * qx + 2 * qx * rsx + rsxx);
+    m.syy = (uint64_t)(n64 * qy * qy + 2 * qy * rsy + rsyy);
+    m.szz = (uint64_t)(n64 * qz * qz + 2 * qz * rsz + rszz);
+    m.sxy = n64 * qx * qy + qx * rsy + qy * rsx + rsxy;
+    m.sxz = n64 * qx * qz + qx * rsz + qz * rsx + rsxz;
+    m.syz = n64 * qy * qz + qy * rsz + qz * rsy + rsyz;
+  }
   if (!done || m.n > max_nn || kth_final == ~0ull) {
     const int slot = atomicAdd(fb_count, 1);
     fb_list[slot] = (int32_t)s;
@@ -848,12 +886,19 @@ int launch_knn_normals(bs_ctx* ctx, const GridDev& g, int64_t q_begin, int64_t q
     // SIMD) -- capped to 128 registers the spills (140 bytes of scratch) cost more than the fourth wave brings
     // (66 ms).  BS_KNN_BUFFERED=0 selects the first kernel.
     const bool buffered = getenv("BS_KNN_BUFFERED") ? atoi(getenv("BS_KNN_BUFFERED")) != 0 : true;
-    if (buffered && p.k <= 16)
-      knn_fast2_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                   fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
+    const bool rel32 = r2 <= 32761.0 && !getenv("BS_KNN_MOMENTS64");  // r <= 181 mm (see REL32)
+    if (buffered && p.k <= 16 && rel32)
+      knn_fast2_kernel<16, true><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                         fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
+    else if (buffered && p.k <= 16)
+      knn_fast2_kernel<16, false><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                          fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
+    else if (buffered && rel32)
+      knn_fast2_kernel<32, true><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                         fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
     else if (buffered)
-      knn_fast2_kernel<32><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
-                                                   fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
+      knn_fast2_kernel<32, false><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
+                                                          fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
     else if (p.k <= 16)
       knn_fast_kernel<16><<<xblocks, 256, 0, st>>>(g, q_begin, q_end, p.k, p.max_nn, r2, d_neigh, d_normals,
                                                   fb_list, fb_count, cert_r2, uncert, d_npos, tie_rows);
