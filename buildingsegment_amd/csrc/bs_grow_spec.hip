@@ -1216,7 +1216,9 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
     o.t_start = t_start;
     o.t_end = (int64_t)wall_clock64();
     o.w = w;
-    o.pad5 = 0;
+    // where the wave ran (debug print only): HW_ID bits [15:0] (wave, SIMD, CU, SH, SE) | XCC_ID << 16
+    o.pad5 = (int32_t)((__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xffff) |
+                       ((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf) << 16));
     out[w] = o;
   }
 }
@@ -1847,7 +1849,9 @@ __global__ __launch_bounds__(64) void grow_spec2_kernel(SpecArgs a, const unsign
     o.t_start = t_start;
     o.t_end = (int64_t)wall_clock64();
     o.w = w;
-    o.pad5 = 0;
+    // where the wave ran (debug print only): HW_ID bits [15:0] (wave, SIMD, CU, SH, SE) | XCC_ID << 16
+    o.pad5 = (int32_t)((__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xffff) |
+                       ((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf) << 16));
     out[w] = o;
   }
 }
@@ -2880,10 +2884,11 @@ int launch_region_grow_spec(bs_ctx* ctx, const int32_t* d_xyz, const double* d_n
         }
         std::sort(idx.begin(), idx.end(), [&](int x, int y) { return h_out[x].steps > h_out[y].steps; });
         fprintf(stderr, "[bs]   launch span %.2f ms; longest attempts (w, steps, status, start ms, end ms, us/step):", (t1 - t0) / 1e5);
-        for (size_t q = 0; q < std::min<size_t>(idx.size(), 6); q++) {
+        for (size_t q = 0; q < std::min<size_t>(idx.size(), 12); q++) {
           const PlaneOut& o = h_out[idx[q]];
-          fprintf(stderr, " [%d %ld %d %.2f %.2f %.3f]", idx[q], (long)o.steps, o.status, (o.t_start - t0) / 1e5, (o.t_end - t0) / 1e5,
-                  (o.t_end - o.t_start) / 100.0 / (double)o.steps);
+          fprintf(stderr, " [%d %ld %d %.2f %.2f %.3f xcc%d se%d cu%d simd%d]", idx[q], (long)o.steps, o.status, (o.t_start - t0) / 1e5,
+                  (o.t_end - t0) / 1e5, (o.t_end - o.t_start) / 100.0 / (double)o.steps, (o.pad5 >> 16) & 0xf, (o.pad5 >> 13) & 7,
+                  (o.pad5 >> 8) & 0xf, (o.pad5 >> 4) & 3);
         }
         fprintf(stderr, "\n");
         if (ncand > 20000) {
