@@ -64,6 +64,8 @@ injects a CPU backend of its own.
 from __future__ import annotations
 
 import math
+import os
+import sys
 import time
 
 import numpy as np
@@ -277,6 +279,12 @@ class DevBackend:
 # the sharded pass
 # --------------------------------------------------------------------------
 
+def _sample_positions(m: int, samples: int, dev) -> torch.Tensor:
+    """`samples` evenly spaced positions in [0, m-1].  Integer arithmetic: a float32 linspace rounds m - 1 UP once m
+    exceeds 2^24 -- an index one past the end, a device-side assertion at 25 M points per rank."""
+    return (torch.arange(samples, dtype=torch.int64, device=dev) * (m - 1)) // max(samples - 1, 1)
+
+
 def _partition(rows: torch.Tensor, world: int, group=None, samples: int = 1024):
     """rows [m,4] = x,y,z,gidx (int32).  Moves every point to its Morton-slab owner."""
     dev = rows.device
@@ -294,8 +302,7 @@ def _partition(rows: torch.Tensor, world: int, group=None, samples: int = 1024):
     m = int(rows.shape[0])
     # splitters: every rank contributes `samples` evenly spaced keys of its sorted local order
     if m:
-        pos = torch.linspace(0, m - 1, samples, device=dev).round().to(torch.int64)
-        samp = skeys[pos]
+        samp = skeys[_sample_positions(m, samples, dev)]
     else:
         samp = torch.full((samples,), big, dtype=torch.int64, device=dev)
     allsamp = torch.sort(all_gather_rows(samp, group)).values
@@ -522,9 +529,13 @@ def segment_sharded_dev(backend, d_xyz: torch.Tensor, d_gidx: torch.Tensor, n_to
     k = params.k
     st = {}
 
+    trace = bool(os.environ.get("BS_DIST_TRACE"))
+
     def tick(name, t0):
         _sync(d_xyz)
         st[name] = st.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        if trace:  # developer aid: which stage a rank had finished when something went wrong
+            print(f"[dist r{rank}] {name} done ({st[name]:.0f} ms)", file=sys.stderr, flush=True)
         return time.perf_counter()
 
     t0 = time.perf_counter()

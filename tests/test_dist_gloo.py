@@ -217,3 +217,18 @@ def test_morton_partition_is_a_partition():
     assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     k = bsd.morton_keys(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], np.int32))
     assert k.tolist() == [0, 1, 2, 4, 7]
+
+
+def test_splitter_sample_positions_stay_in_range_beyond_2_pow_24():
+    """The slab splitters are sampled at evenly spaced positions of the sorted keys; computed in float32 the last
+    position was m (one past the end) as soon as a rank held more than 2^24 points -- bench.py --gpus 2 on the 50 M
+    cloud died with a device-side assertion."""
+    import torch
+    from buildingsegment_amd import dist as D
+    for m in (1, 2, 1000, (1 << 24) - 1, (1 << 24) + 1, 25_000_000, 50_000_000, (1 << 31) - 2):
+        for samples in (1, 2, 1024):
+            pos = D._sample_positions(m, samples, torch.device("cpu"))
+            assert pos.dtype == torch.int64 and len(pos) == samples
+            assert int(pos.min()) == 0 and int(pos.max()) <= m - 1
+            if samples > 1:
+                assert int(pos[-1]) == m - 1 and bool((pos[1:] >= pos[:-1]).all())
