@@ -348,11 +348,14 @@ int rccl_all_to_all_v(void* h, const void* d_send, const int64_t* sb, void* d_re
     return 1;
   int64_t so = 0, ro = 0;
   bool bad = false;
+  // (a block travels in pieces of at most 1 GiB: a 3.2 GB payload came back incomplete from ONE all-to-all over RCCL
+  // through torch.distributed -- byte counts beyond 2^31; sender and receiver cut a block at the same places)
+  const int64_t piece = (int64_t)1 << 30;
   for (int r = 0; r < c->world; r++) {
-    if (sb[r] > 0)
-      bad = bad || R.Send((const char*)d_send + so, (size_t)sb[r], ncclChar, r, c->comm, (hipStream_t)stream) != ncclSuccess;
-    if (rb[r] > 0)
-      bad = bad || R.Recv((char*)d_recv + ro, (size_t)rb[r], ncclChar, r, c->comm, (hipStream_t)stream) != ncclSuccess;
+    for (int64_t o = 0; o < sb[r]; o += piece)
+      bad = bad || R.Send((const char*)d_send + so + o, (size_t)std::min(piece, sb[r] - o), ncclChar, r, c->comm, (hipStream_t)stream) != ncclSuccess;
+    for (int64_t o = 0; o < rb[r]; o += piece)
+      bad = bad || R.Recv((char*)d_recv + ro + o, (size_t)std::min(piece, rb[r] - o), ncclChar, r, c->comm, (hipStream_t)stream) != ncclSuccess;
     so += sb[r];
     ro += rb[r];
   }

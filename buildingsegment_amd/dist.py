@@ -122,6 +122,7 @@ def partition_morton(xyz: np.ndarray, world: int, rank: int):
 # same calls on the host copy `_coll` makes)
 # --------------------------------------------------------------------------
 
+A2A_MAX_BYTES = 1 << 30  # payload of one (source, destination) block per all_to_all_single call (see all_to_all_rows)
 FORCE_COLLECTIVES = False  # tests: issue the collectives even at world size 1 (the nccl branch on a one-GPU box)
 
 
@@ -197,7 +198,33 @@ def all_to_all_rows(rows: torch.Tensor, send_counts: torch.Tensor, group=None):
     r_list = [int(v) for v in rc.tolist()]
     src = _coll(rows.contiguous(), group)
     out = torch.empty((sum(r_list),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=src.device)
-    dist.all_to_all_single(out, src, output_split_sizes=r_list, input_split_sizes=s_list, group=group)
+    # One call moves at most A2A_MAX_BYTES per (source, destination) block: a 3.2 GB payload (50 M rows of 16 int32)
+    # came back incomplete from all_to_all_single over RCCL (measured at world 1; byte counts beyond 2^31).  Every
+    # block is cut into the same number of parts on both sides (floor(c s / P) boundaries), P agreed on by all ranks.
+    row_bytes = max(1, int(rows[0].numel()) * rows.element_size()) if rows.shape[0] else max(1, rows.element_size())
+    max_rows = max(1, A2A_MAX_BYTES // row_bytes)
+    need = torch.tensor([max([(v + max_rows - 1) // max_rows for v in s_list + r_list] + [1])], dtype=torch.int64, device=sc.device)
+    dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+    parts = int(need.item())
+    if parts == 1:
+        dist.all_to_all_single(out, src, output_split_sizes=r_list, input_split_sizes=s_list, group=group)
+        return out.to(rows.device), r_list
+    s_base = np.concatenate([[0], np.cumsum(s_list)]).astype(np.int64)
+    r_base = np.concatenate([[0], np.cumsum(r_list)]).astype(np.int64)
+    for c in range(parts):
+        s_lo = [(c * v) // parts for v in s_list]
+        s_hi = [((c + 1) * v) // parts for v in s_list]
+        r_lo = [(c * v) // parts for v in r_list]
+        r_hi = [((c + 1) * v) // parts for v in r_list]
+        piece = torch.cat([src[int(s_base[d]) + s_lo[d]:int(s_base[d]) + s_hi[d]] for d in range(len(s_list))])
+        got = torch.empty((sum(h - l for l, h in zip(r_lo, r_hi)),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=src.device)
+        dist.all_to_all_single(got, piece, output_split_sizes=[h - l for l, h in zip(r_lo, r_hi)],
+                               input_split_sizes=[h - l for l, h in zip(s_lo, s_hi)], group=group)
+        o = 0
+        for r in range(len(r_list)):
+            w = r_hi[r] - r_lo[r]
+            out[int(r_base[r]) + r_lo[r]:int(r_base[r]) + r_hi[r]] = got[o:o + w]
+            o += w
     return out.to(rows.device), r_list
 
 
