@@ -322,6 +322,22 @@ def test_first_knn_kernel_is_bit_identical(gpu_ctx, oracle, monkeypatch):
         _check_knn_normals(gpu_ctx, oracle, xyz, k)
 
 
+def test_knn_moment_sums_64_bit_and_relative_32_bit_agree(gpu_ctx, oracle, monkeypatch):
+    """The default kernel keeps the moment sums relative to the query in 32-bit registers when r <= 181 mm and in 64-bit
+    absolute sums otherwise (BS_KNN_MOMENTS64=1 forces the latter): normals must equal the oracle's bit for bit either
+    way, also for a cloud far from the origin (large absolute coordinates, the conversion's worst case)."""
+    far = synth.urban(100_000, seed=8) + np.array([8_000_000, -8_000_000, 7_500_000], np.int32)
+    cases = ((synth.urban(120_000, seed=8), 16, {}), (far, 16, {}), (synth.uniform(40000, seed=21), 32, {}),
+             (synth.urban(120_000, seed=8), 16, {"radius": 250.0}), (far, 15, {"radius": 181.0}), (far, 15, {"radius": 182.0}))
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("BS_KNN_MOMENTS64", env)
+        else:
+            monkeypatch.delenv("BS_KNN_MOMENTS64", raising=False)
+        for xyz, k, kw in cases:
+            _check_knn_normals(gpu_ctx, oracle, xyz, k, **kw)
+
+
 def test_general_knn_by_the_wave_and_by_the_thread_agree(gpu_ctx, oracle, monkeypatch):
     """Work-listed queries (more than max_nn points inside the radius, or uncertified within the fast kernel's rings) go to
     knn_general_wave_kernel and from there -- buffer overflow, still uncertified -- to the one-thread kernel.  Dense
