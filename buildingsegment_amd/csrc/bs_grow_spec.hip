@@ -1278,7 +1278,9 @@ __global__ __launch_bounds__(64) void grow_spec_kernel(SpecArgs a, const unsigne
 //    instructions per 64 candidates): in the micro-benchmark 920-1 000 cycles against 890 for the nine per-lane loads
 //    with one wave per CU -- it only pays at 8+ waves per CU (3 200 against 4 600), where the launches are not bound;
 //  * s_setprio 3 for attempts past 512 steps (the launch ends with its longest plane): urban 10 M 113.0 vs 108.7 ms,
-//    50 M 186.5 vs 181.4 ms.
+//    50 M 186.5 vs 181.4 ms;
+//  * two steps per trip of the hot loop (the back edge is a cascade of exit-flag blocks, ~35 scalar instructions and
+//    five taken branches): facade 122.6 vs 120.6-123 ms -- nothing.
 // What bounds a step (stamps of this engine on facade 1 M, cycles: pop + issue 510, plane state 700 over it, wait 150,
 // test + classification 265, claims 390, list ring 305, push 150, loop control and exits 360 = 2 900) is the wave's own
 // instruction stream -- one wave issues one instruction every ~6 cycles, and every phase consumes what the one before
