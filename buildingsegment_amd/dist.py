@@ -557,12 +557,15 @@ def segment_sharded_dev(backend, d_xyz: torch.Tensor, d_gidx: torch.Tensor, n_to
     st = {}
 
     trace = bool(os.environ.get("BS_DIST_TRACE"))
+    if os.environ.get("BS_DIST_TRACE") == "2":  # developer aid: where is a rank after 45 s in one pass?
+        import faulthandler
+        faulthandler.dump_traceback_later(45, repeat=False, file=sys.stderr)
 
     def tick(name, t0):
         _sync(d_xyz)
         st[name] = st.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
         if trace:  # developer aid: which stage a rank had finished when something went wrong
-            print(f"[dist r{rank}] {name} done ({st[name]:.0f} ms)", file=sys.stderr, flush=True)
+            print(f"[dist r{rank}] {name} done ({st[name]:.0f} ms) at {time.time() % 1000:.2f}", file=sys.stderr, flush=True)
         return time.perf_counter()
 
     t0 = time.perf_counter()
