@@ -191,7 +191,7 @@ __device__ inline bool slab_ensure(const Pool& pool, Slab& s, int32_t used, int6
 // leaves the window takes the global atomic.
 constexpr int RW_PAD = 896;
 constexpr int RW_WIN = 256 + 2 * RW_PAD;  // 2048 positions
-constexpr int GW_PAD = 384;               // geometry tile of static_mask_kernel: 1024 positions x 48 B = 48 KB of LDS (56 KB with the counters: static LDS stays below 64 KB)
+constexpr int GW_PAD = 192;               // geometry tile of static_mask_kernel: 640 positions x 48 B = 30 KB of LDS (38 KB with the counters).  Measured at 50 M: padding 384 (48 KB, two workgroups per CU) 7.97 ms, 192 5.42 ms, 128 5.43 ms
 constexpr int GW_WIN = 256 + 2 * GW_PAD;
 
 // Static depth-0 masks.  One workgroup = 256 consecutive positions.  The geometry (position + normal, 48 B)
