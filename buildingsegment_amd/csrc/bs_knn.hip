@@ -232,10 +232,11 @@ __global__ __launch_bounds__(256) void knn_fast_kernel(GridDev g, int64_t q_begi
   }
 }
 
-// (the <16, REL32> instance is held to 128 registers, 4 waves per SIMD, at the price of 48 bytes of scratch: uniform 10 M
-// 10.8 against 11.5 ms, urban 50 M 27.7 against 27.3 ms; -DBS_KNN_CAP4=0 builds it uncapped)
+// (-DBS_KNN_CAP4=1 holds the <16, REL32> instance to 128 registers, 4 waves per SIMD, at the price of 48 bytes of
+// scratch: uniform 10 M 10.8 against 11.5 ms, urban 50 M 27.7 against 27.3 ms -- and 27.7 instead of 14.7 GB of
+// fabric traffic per 50 M pass (PMC): the spills; not the default)
 #ifndef BS_KNN_CAP4
-#define BS_KNN_CAP4 1
+#define BS_KNN_CAP4 0
 #endif
 constexpr int KBUF = 8;  // waiting candidates per thread of knn_fast2_kernel
 
