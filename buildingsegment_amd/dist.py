@@ -122,7 +122,7 @@ def partition_morton(xyz: np.ndarray, world: int, rank: int):
 # same calls on the host copy `_coll` makes)
 # --------------------------------------------------------------------------
 
-A2A_MAX_BYTES = 1 << 30  # payload of one (source, destination) block per all_to_all_single call (see all_to_all_rows)
+A2A_MAX_BYTES = 1 << 30  # payload of one all_to_all_single call (see all_to_all_rows)
 FORCE_COLLECTIVES = False  # tests: issue the collectives even at world size 1 (the nccl branch on a one-GPU box)
 
 
@@ -198,11 +198,11 @@ def all_to_all_rows(rows: torch.Tensor, send_counts: torch.Tensor, group=None):
     r_list = [int(v) for v in rc.tolist()]
     src = _coll(rows.contiguous(), group)
     out = torch.empty((sum(r_list),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=src.device)
-    # One call moves at most A2A_MAX_BYTES per (source, destination) block: a 3.2 GB payload (50 M rows of 16 int32)
+    # One call moves at most A2A_MAX_BYTES in total (every block at most 1/world of it): a 3.2 GB payload (50 M rows of 16 int32)
     # came back incomplete from all_to_all_single over RCCL (measured at world 1; byte counts beyond 2^31).  Every
     # block is cut into the same number of parts on both sides (floor(c s / P) boundaries), P agreed on by all ranks.
     row_bytes = max(1, int(rows[0].numel()) * rows.element_size()) if rows.shape[0] else max(1, rows.element_size())
-    max_rows = max(1, A2A_MAX_BYTES // row_bytes)
+    max_rows = max(1, A2A_MAX_BYTES // (row_bytes * max(len(s_list), 1)))  # (the whole call stays below the limit)
     need = torch.tensor([max([(v + max_rows - 1) // max_rows for v in s_list + r_list] + [1])], dtype=torch.int64, device=sc.device)
     dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
     parts = int(need.item())
