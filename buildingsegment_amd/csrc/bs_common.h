@@ -188,7 +188,7 @@ struct bs_ctx {
   // pipeline for the same cloud / k / neigh buffer: the grower takes them instead of translating indices
   bs::DevBuf seg_npos;
   // scratch of the sharded pass (bs_sharded.hip): named by use there
-  bs::DevBuf sh[24];
+  bs::DevBuf sh[25];  // (24 scratch buffers of bs_sharded.hip + the look-up table of bs_remap_rows_dev)
   std::vector<int32_t> sh_seeds;  // all committed seeds of the last bs_segment_sharded (global indices, ascending)
   int64_t sh_nloc = 0;            // points this rank grew
   bool sh_valid = false;
